@@ -1,0 +1,102 @@
+/*
+ * cmpc.h -- C ABI of the MI355X batched centroidal-MPC solver (libcmpc_amd.so).
+ *
+ * Drop-in boundary for the hot path of the reference:
+ *   code/centroidal_mpc_vertices.py:606   sol = self.opt.solve()          (CasADi Opti -> IPOPT)
+ *   code/centroidal_mpc_vertices.py:126-353  NLP definition (constants -> cmpc_spec)
+ *   code/centroidal_mpc_vertices.py:511-600  opt.set_value(...)           (-> parameter record)
+ *   code/centroidal_mpc_vertices.py:614-617,630-631  sol.value / set_initial (-> out_XU / warm_XU)
+ * and the same lines of code/centroidal_mpc_vertices_payload.py (gains k1,k2 = 7,1 at :27-31).
+ *
+ * The reference has no native interface for this path (it reaches IPOPT through
+ * CasADi's SWIG layer); this header is what a ctypes stub binds instead
+ * (INTEGRATION.md).  Plain pointers and sizes only; every pointer passed to
+ * cmpc_solve_batch is a DEVICE pointer owned by the caller
+ * (torch.Tensor.data_ptr()).  All functions return 0 on success, non-zero on
+ * error (message via cmpc_last_error).  Kernels never throw; per-instance
+ * outcome is reported in status[].
+ */
+#ifndef CMPC_H
+#define CMPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMPC_NX 20            /* reference state size (:164-166)                      */
+#define CMPC_MAX_N 64         /* horizon limit of this build                          */
+
+/* Problem constants shared by a batch.  Defaults = the literals of the reference. */
+typedef struct cmpc_spec {
+  int32_t N;                  /* horizon, params['N'] (:10)                           */
+  int32_t nv;                 /* contact vertices per foot: 4 (reference, :55-60) or 8 */
+  int32_t max_iter;           /* interior-point iteration cap                         */
+  int32_t reserved;
+  double delta;               /* world_time_step*mpc_rate (:11)                       */
+  double g;                   /* params['g'] (:18)                                    */
+  double k1, k2;              /* change-of-coordinates gains (:27-31)                 */
+  double w_rate;              /* force-rate weight (:339-341)                         */
+  double w_hw;                /* 1000 (:312)                                          */
+  double w_cxy;               /* 1 (:313-314)                                         */
+  double w_cz_const;          /* 2000 (:302-305): w_z[i] = 1000*exp(-i)+1000          */
+  double w_foot;              /* 1000 (:316-319)                                      */
+  double w_force;             /* 10 (:320-335)                                        */
+  double cz_max;              /* 0.76 (:230)                                          */
+  double box[3];              /* 0.01, 0.005, 0.00005 (:259-271)                      */
+  double foot_length;         /* 0.25 (:51)                                           */
+  double foot_width;          /* 0.13 (:52)                                           */
+  double prox;                /* proximal weight on U (build-defined)      */
+  double relax;               /* inequality relaxation, IPOPT bound_relax_factor 1e-8 */
+  double tol;                 /* scaled KKT tolerance                                 */
+} cmpc_spec;
+
+/* Doubles per instance in the parameter / solution records. */
+#define CMPC_NREC(N) (24 + 19 * (N))
+#define CMPC_NU(nv) (6 * (nv) + 8)
+#define CMPC_NSOL(N, nv) (CMPC_NX * ((N) + 1) + CMPC_NU(nv) * (N))
+
+/* Per-instance outcome. */
+enum {
+  CMPC_CONVERGED = 0,         /* scaled KKT error <= tol                               */
+  CMPC_MAX_ITER = 1,          /* iteration cap reached                                 */
+  CMPC_NUMERICAL = 2          /* regularisation exhausted / non-finite iterate         */
+};
+
+typedef struct cmpc_handle cmpc_handle;
+
+/* Fill *spec with the reference's constants for horizon N, nv vertices per foot. */
+void cmpc_default_spec(cmpc_spec *spec, int32_t N, int32_t nv);
+
+/* Create a solver bound to HIP device `device` (one handle per GPU / per stream). */
+int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out);
+int cmpc_destroy(cmpc_handle *h);
+
+/* Device scratch the handle allocates lazily for a batch of B instances. */
+size_t cmpc_workspace_bytes(const cmpc_spec *spec, int32_t B);
+
+/*
+ * Solve B independent instances.
+ *   params   [B][CMPC_NREC(N)]        parameter records (layout: DESIGN.md / problem.py)
+ *   warm_XU  [B][CMPC_NSOL(N,nv)]     previous solution (initial guess and proximal centre); may be NULL
+ *   out_XU   [B][CMPC_NSOL(N,nv)]     X (20 x (N+1), column-major) then U (nu x N, column-major)
+ *   status   [B]  CMPC_* code;  iters [B] iterations used;  kkt_res [B] final scaled KKT error
+ *   stream   hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing.
+ */
+int cmpc_solve_batch(cmpc_handle *h, int32_t B, const double *params, const double *warm_XU,
+                     double *out_XU, int32_t *status, int32_t *iters, double *kkt_res,
+                     void *stream);
+
+/* Average kernel time (ms) of the last cmpc_solve_batch on this handle, measured with
+ * HIP events on the launch stream; synchronises that stream. */
+int cmpc_last_kernel_ms(cmpc_handle *h, float *ms);
+
+const char *cmpc_last_error(cmpc_handle *h);
+const char *cmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMPC_H */

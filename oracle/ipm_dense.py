@@ -1,0 +1,131 @@
+"""TEST INFRASTRUCTURE ONLY -- slow, independent full-space interior-point solver.
+
+Solves the literal NLP of oracle/nlp_reference.py with autograd derivatives and
+dense KKT factorisations (no Riccati, no stage structure, no hand derivatives).
+It exists to cross-check oracle/cmpc_oracle.c, which shares its algorithmic
+structure with the HIP solver.  Never imported by the product path.
+
+Algorithm: monotone-barrier primal-dual interior point (Fiacco-McCormick barrier
+schedule as in IPOPT's default mode), exact Lagrangian Hessian with inertia
+correction (delta_w * I), l1-merit backtracking line search.
+"""
+import numpy as np
+import scipy.linalg as sla
+import torch
+
+from . import nlp_reference as nlp
+
+
+def _inertia_ok(K, nw, ne):
+    _, d, _ = sla.ldl(K)
+    ev = np.linalg.eigvalsh(d)
+    return int((ev > 0).sum()) == nw and int((ev < 0).sum()) == ne
+
+
+def solve(spec, par, w0=None, u_prox=None, tol=1e-9, max_iter=300, verbose=False,
+          mu0=0.1, hessian="exact", linesearch=True):
+    """Returns dict(w, iters, kkt, status, lam, z, s).  status 0 = converged."""
+    N = spec.N
+    nw = nlp.NX * (N + 1) + spec.nu * N
+    w = np.zeros(nw) if w0 is None else np.array(w0, dtype=np.float64)
+
+    def evaluate(wv):
+        wt = torch.tensor(wv)
+        return (nlp.cost(spec, par, wt, u_prox).item(), nlp.equalities(spec, par, wt).numpy(),
+                nlp.inequalities(spec, par, wt).numpy())
+
+    _, c0, g0 = evaluate(w)
+    ne, ni = c0.size, g0.size
+    s = np.maximum(-g0, 1e-2)
+    mu = mu0
+    z = mu / s
+    lam = np.zeros(ne)
+    nu_pen = 1.0
+    reg_last = 0.0
+    status, kkt, it = 1, np.inf, 0
+    for it in range(max_iter):
+        wt = torch.tensor(w, requires_grad=True)
+        f = nlp.cost(spec, par, wt, u_prox)
+        gradf = torch.autograd.grad(f, wt)[0].numpy()
+        f = f.item()
+        Jc = torch.autograd.functional.jacobian(lambda v: nlp.equalities(spec, par, v), wt.detach(),
+                                                vectorize=True).numpy()
+        Jg = torch.autograd.functional.jacobian(lambda v: nlp.inequalities(spec, par, v), wt.detach(),
+                                                vectorize=True).numpy()
+        _, c, g = evaluate(w)
+        lam_t, z_t = torch.tensor(lam), torch.tensor(z)
+
+        def lagr(v):
+            L = nlp.cost(spec, par, v, u_prox)
+            if hessian == "exact":
+                L = L + (lam_t * nlp.equalities(spec, par, v)).sum() + (z_t * nlp.inequalities(spec, par, v)).sum()
+            return L
+
+        H = torch.autograd.functional.hessian(lagr, wt.detach(), vectorize=True).numpy()
+        rd = gradf + Jc.T @ lam + Jg.T @ z
+        rg = g + s
+        comp = s * z
+        sd = max(100.0, (np.abs(lam).sum() + np.abs(z).sum()) / (ne + ni)) / 100.0
+        e_d, e_p, e_c0 = np.abs(rd).max() / sd, max(np.abs(c).max(), np.abs(rg).max()), np.abs(comp).max() / sd
+        kkt = max(e_d, e_p, e_c0)
+        if verbose:
+            print(f"it {it:3d} f={f:.8e} d={e_d:.2e} p={e_p:.2e} c={e_c0:.2e} mu={mu:.1e} reg={reg_last:.1e} zmax={z.max():.2e}")
+        if kkt < tol:
+            status = 0
+            break
+        while mu > tol / 10 and max(e_d, e_p, np.abs(comp - mu).max() / sd) < 10 * mu:
+            mu = max(tol / 10, min(0.2 * mu, mu ** 1.5))
+        Sig = z / s
+        Hb = H + Jg.T @ (Sig[:, None] * Jg)
+        reg = 0.0
+        while True:
+            K = np.block([[Hb + reg * np.eye(nw), Jc.T], [Jc, np.zeros((ne, ne))]])
+            if _inertia_ok(K, nw, ne):
+                break
+            reg = (1e-4 if reg_last == 0 else max(1e-20, reg_last / 3)) if reg == 0 else \
+                  reg * (100 if reg_last == 0 else 8)
+            if reg > 1e20:
+                return dict(w=w, iters=it, kkt=kkt, status=2, lam=lam, z=z, s=s)
+        if reg > 0:
+            reg_last = reg
+        rhs_w = -(gradf + Jg.T @ (mu / s + Sig * rg))
+        sol = sla.lu_solve(sla.lu_factor(K), np.concatenate([rhs_w, -c]))
+        dw, lam_new = sol[:nw], sol[nw:]
+        ds = -rg - Jg @ dw
+        dz = (mu - comp - z * ds) / s
+
+        def max_step(v, dv, tau):
+            neg = dv < 0
+            return 1.0 if not neg.any() else min(1.0, (tau * v[neg] / -dv[neg]).min())
+
+        tau = max(0.99, 1 - mu)
+        ap, ad = max_step(s, ds, tau), max_step(z, dz, tau)
+        # l1 merit on (w, s)
+        infeas = np.abs(c).sum() + np.abs(rg).sum()
+        dphi_obj = gradf @ dw - mu * (ds / s).sum()
+        quad = dw @ (Hb + reg * np.eye(nw)) @ dw
+        if infeas > 0:
+            nu_need = (dphi_obj + 0.5 * max(quad, 0.0)) / (0.9 * infeas)
+            if nu_pen < nu_need:
+                nu_pen = nu_need + 1.0
+        dphi = dphi_obj - nu_pen * infeas
+
+        def merit(wv, sv):
+            fv, cv, gv = evaluate(wv)
+            return fv - mu * np.log(sv).sum() + nu_pen * (np.abs(cv).sum() + np.abs(gv + sv).sum())
+
+        phi0 = merit(w, s)
+        a = ap
+        for _ in range(30 if linesearch else 0):
+            if merit(w + a * dw, s + a * ds) <= phi0 + 1e-8 * a * dphi + 1e-12 * abs(phi0):
+                break
+            a *= 0.5
+        w = w + a * dw
+        s = s + a * ds
+        lam = lam + a * (lam_new - lam)
+        z = z + ad * dz
+        # keep z within a factor of mu/s (IPOPT's kappa_sigma safeguard)
+        z = np.clip(z, mu / s / 1e10, mu / s * 1e10)
+        if verbose and a < ap:
+            print(f"      (step {a:.2e} of {ap:.2e})")
+    return dict(w=w, iters=it, kkt=kkt, status=status, lam=lam, z=z, s=s)
