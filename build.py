@@ -1,0 +1,62 @@
+"""Build every native artefact in-tree (HIP library for gfx950, C oracle, host-emulation harness)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "online-non-linear-centroidal-mpc-with-stability-guarantees-for-robust-locomotion-of-legged-robots-_amd")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_hip(force=False, verbose=False):
+    src = os.path.join(PKG, "csrc", "cmpc_hip.hip")
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(ROOT, "include", "cmpc.h")]
+    out = os.path.join(PKG, "libcmpc_amd.so")
+    if force or _newer(out, deps):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out, src]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        subprocess.check_call(cmd)
+    return out
+
+
+def build_hip_profile(force=False):
+    """Diagnostic variant with in-kernel phase timers (tools/ only; never loaded by the package)."""
+    src = os.path.join(PKG, "csrc", "cmpc_hip.hip")
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(ROOT, "include", "cmpc.h")]
+    out = os.path.join(ROOT, "tools", "libcmpc_amd_prof.so")
+    if force or _newer(out, deps):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               "-DCMPC_PROFILE", "-o", out, src])
+    return out
+
+
+def build_oracle(force=False):
+    out = os.path.join(ROOT, "oracle", "libcmpc_oracle.so")
+    deps = [os.path.join(ROOT, "oracle", "cmpc_oracle.c"), os.path.join(ROOT, "include", "cmpc.h")]
+    if force or _newer(out, deps):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "libcmpc_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return out
+
+
+def build_emu(force=False):
+    src = os.path.join(ROOT, "tests", "emu", "cmpc_emu.cpp")
+    out = os.path.join(ROOT, "tests", "emu", "libcmpc_emu.so")
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(ROOT, "include", "cmpc.h")]
+    if force or _newer(out, deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", out, src])
+    return out
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    print(build_hip(force, verbose="-v" in sys.argv))
+    print(build_oracle(force))
+    print(build_emu(force))

@@ -1,0 +1,1164 @@
+// cmpc_kernel.hpp -- device code of the batched centroidal-MPC solver (gfx950 / CDNA4).
+//
+// One wavefront (one 64-thread workgroup) owns one problem instance at a time and walks the
+// horizon serially; the 64 lanes share every stage's small dense blocks through LDS:
+//   * lane i owns row i of the stage KKT block  M = H_k + [B A]' P_{k+1} [B A]   (packed lower
+//     triangle in LDS: triangular row offsets are a permutation mod 32, so column sweeps of
+//     64-bit words are bank-conflict free),
+//   * the factorisation  M_uu = L L',  Ls = M_xu L^-T,  P_k = M_xx - Ls Ls'  runs in LDS,
+//   * factors / gains of all stages spill to a per-workgroup global scratch slab that is written
+//     and re-read with unit stride (lane = fastest index).
+// Algorithm (identical to oracle/cmpc_oracle.c, which restates the reference NLP
+// code/centroidal_mpc_vertices.py:126-353, :371-461): primal-dual interior point with a
+// monotone barrier schedule, exact Lagrangian Hessian, Riccati recursion with inertia-correcting
+// regularisation, fraction-to-the-boundary steps.
+//
+// The same source is compiled (a) by hipcc for the product library and (b) by g++ under
+// -DCMPC_HOST_EMU for the CPU test harness (tests/emu), where the 64 lanes are OS threads and
+// CMPC_SYNC() is a real barrier: every cross-lane LDS hand-off therefore carries an explicit
+// barrier.
+#pragma once
+#include "../../include/cmpc.h"
+#include <math.h>
+
+#ifndef CMPC_HOST_EMU
+#include <hip/hip_runtime.h>
+#define CMPC_DEV __device__ __forceinline__
+#define CMPC_DEVN __device__ __noinline__
+#define CMPC_LANE ((int)threadIdx.x)
+#ifdef CMPC_EXPERIMENT_INV
+#define CMPC_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+#else
+#define CMPC_SYNC() __syncthreads()
+#endif
+#endif
+
+// Optional phase timers (diagnostic build only, -DCMPC_PROFILE): cycles per phase summed over the
+// launch, written to a buffer nothing else reads.
+#if defined(CMPC_PROFILE) && !defined(CMPC_HOST_EMU)
+#define CMPC_TICK(slot) do { long long now_ = clock64(); tprof[slot] += now_ - tlast; tlast = now_; } while (0)
+#define CMPC_TICK_RESET() do { tlast = clock64(); } while (0)
+#else
+#define CMPC_TICK(slot) do { } while (0)
+#define CMPC_TICK_RESET() do { } while (0)
+#endif
+
+namespace cmpc {
+
+struct KArgs {
+  cmpc_spec sp;
+  int B;
+  const double *recs;   // [B][nrec]
+  const double *warm;   // [B][nsol] or null
+  double *out;          // [B][nsol]
+  int32_t *status;
+  int32_t *iters;
+  double *kkt;
+  double *scratch;      // [grid][scratch_stride]
+  size_t scratch_stride;
+  long long *prof;      // [8] phase cycle sums (CMPC_PROFILE builds), else null
+  double *dbg;          // diagnostic dump of instance 0's full iterate (x, lam, s, z), else null
+};
+
+enum { R_LYAP = 0, R_CZ = 1, R_HWC = 2, R_BOX = 3, R_FRIC = 15 };
+
+// termination safeguards (same constants as the oracle)
+constexpr double ACC_FACTOR = 100.0;
+constexpr int ACC_ITERS = 8;
+constexpr double STALL_STEP = 1e-7;
+constexpr int STALL_ITERS = 6;
+// Newton iterations at the final barrier value after the tolerance is first met (see the oracle)
+constexpr int POLISH_ITERS = 2;
+
+template <int NV> struct Dims {
+  static constexpr int NF = 2 * NV;           // contact vertices
+  static constexpr int NU = 6 * NV + 8;
+  static constexpr int NXA = CMPC_NX + 2 * NV;
+  static constexpr int NZ = NU + NXA;
+  static constexpr int NI = 15 + 10 * NV;
+  static constexpr int NTRI = NZ * (NZ + 1) / 2;
+  static constexpr int PS = NXA + 1;          // odd row strides: conflict-free column access
+  static constexpr int LS = NU + 1;
+  static constexpr int TH = (NZ + 1) / 2;     // columns per half of T = P [B A]
+  static constexpr int TS = TH | 1;
+  // ---- LDS map (doubles) ----
+  static constexpr int oM = 0;
+  static constexpr int oT = oM + NTRI + (NTRI & 1);
+  static constexpr int oP = oT + NXA * TS + ((NXA * TS) & 1);
+  static constexpr int oXK = oP + NXA * PS + ((NXA * PS) & 1);
+  static constexpr int oUK = oXK + NXA;
+  static constexpr int oXN1 = oUK + NU;
+  static constexpr int oLAMK = oXN1 + NXA;
+  static constexpr int oLAMN = oLAMK + NXA;
+  static constexpr int oSK = oLAMN + NXA;
+  static constexpr int oZK = oSK + NI;
+  static constexpr int oGK = oZK + NI;
+  static constexpr int oW0 = oGK + NI;        // sigma = z/s
+  static constexpr int oW1 = oW0 + NI;        // sigma*(g+s)
+  static constexpr int oW2 = oW1 + NI;        // 1/s
+  static constexpr int oVR = oW2 + NI;        // r_j   (NF x 3)
+  static constexpr int oVDV = oVR + 3 * NF;   // R' v_j
+  static constexpr int oVRV = oVDV + 3 * NF;  // R v_j
+  static constexpr int oMISC = oVRV + 3 * NF; // 64 scalars
+  static constexpr int oAL = oMISC + 64;      // Lyapunov gradient (NZ)
+  static constexpr int oHO = oAL + NZ;
+  static constexpr int oGH = oHO + NZ;        // rows 6..8 of [B A] without identity (3 x NZ)
+  static constexpr int oBV = oGH + 3 * NZ;
+  static constexpr int oPC = oBV + NXA;
+  static constexpr int oTV = oPC + NXA;       // NZ temp
+  static constexpr int oUPX = oTV + NZ;
+  static constexpr int oSR = oUPX + NU;       // stage record k (19), k-1 (19), header (24)
+  static constexpr int oSRP = oSR + 20;
+  static constexpr int oHDR = oSRP + 20;
+  static constexpr int oRED = oHDR + 24;      // 64 reduction slots
+  static constexpr int LDS_DOUBLES = oRED + 64;
+  // ---- global scratch map per stage (doubles) ----
+  static constexpr int gLAM = 0;
+  static constexpr int gLS = gLAM + NU * NU;
+  static constexpr int gPK = gLS + NXA * NU;
+  static constexpr int gH0 = gPK + NXA * NXA;
+  static constexpr int gH1 = gH0 + NZ;
+  static constexpr int gAL = gH1 + NZ;
+  static constexpr int gGH = gAL + NZ;
+  static constexpr int gB = gGH + 3 * NZ;
+  static constexpr int gPB = gB + NXA;
+  static constexpr int gPV = gPB + NXA;
+  static constexpr int gL = gPV + NXA;
+  static constexpr int gG = gL + NU;
+  static constexpr int STAGE = ((gG + NI + 7) / 8) * 8;
+  // iterate arrays follow the (N+1) stage blocks
+  static size_t scratch_doubles(int N) {
+    size_t n = (size_t)(N + 1) * STAGE;
+    n += (size_t)(N + 1) * NXA * 4;   // x, lam, dx, lamn
+    n += (size_t)(N + 1) * NU * 3;    // u, du, uprox
+    n += (size_t)(N + 1) * NI * 4;    // s, z, ds, dz
+    return (n + 7) / 8 * 8;
+  }
+};
+
+#ifndef CMPC_NO_DEVICE_CODE
+
+CMPC_DEV int tri(int i) { return i * (i + 1) / 2; }
+
+template <int NV> struct Solver {
+  using D = Dims<NV>;
+  static constexpr int NF = D::NF, NU = D::NU, NXA = D::NXA, NZ = D::NZ, NI = D::NI;
+
+  const KArgs &ka;
+  const cmpc_spec &sp;
+  double *lds;
+  double *gs;              // this workgroup's scratch slab
+  const double *rec;       // this instance's parameter record
+  int N, lane;
+  // global iterate arrays
+  double *gx, *glam, *gdx, *glamn, *gu, *gdu, *gupx, *gsl, *gz, *gds, *gdz;
+  // per-lane column list of [B A]: rows / coefficients (id, h0, h1, h2, sp1, sp2)
+  int lr[6];
+  double lg[6];
+  long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  bool dbg_on = false;
+
+  CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
+      : ka(a), sp(a.sp), lds(l), gs(g), rec(r), N(a.sp.N), lane(CMPC_LANE) {
+    double *p = gs + (size_t)(N + 1) * D::STAGE;
+    gx = p; p += (size_t)(N + 1) * NXA;
+    glam = p; p += (size_t)(N + 1) * NXA;
+    gdx = p; p += (size_t)(N + 1) * NXA;
+    glamn = p; p += (size_t)(N + 1) * NXA;
+    gu = p; p += (size_t)(N + 1) * NU;
+    gdu = p; p += (size_t)(N + 1) * NU;
+    gupx = p; p += (size_t)(N + 1) * NU;
+    gsl = p; p += (size_t)(N + 1) * NI;
+    gz = p; p += (size_t)(N + 1) * NI;
+    gds = p; p += (size_t)(N + 1) * NI;
+    gdz = p;
+  }
+  CMPC_DEV double *stage(int k) const { return gs + (size_t)k * D::STAGE; }
+  CMPC_DEV double &L(int o) const { return lds[o]; }
+
+  // contact flag gamma_f at node k and k-1 from the staged records
+  CMPC_DEV double gam_k(int k, int f) const { return (k == N) ? L(D::oHDR + 22 + f) : L(D::oSR + 17 + f); }
+  CMPC_DEV double gam_km1(int f) const { return L(D::oSRP + 17 + f); }
+  CMPC_DEV double w_cz(int i) const {
+    double half = sp.w_cz_const * 0.5;
+    return (sp.w_cz_const - half) * exp(-(double)i) + half;
+  }
+  CMPC_DEV void vert_local(int j, double &vx, double &vy) const {
+    const double Lh = sp.foot_length * 0.5, Wh = sp.foot_width * 0.5;
+    const double cx[8] = {Lh, Lh, -Lh, -Lh, Lh, 0.0, -Lh, 0.0};
+    const double cy[8] = {Wh, -Wh, -Wh, Wh, 0.0, -Wh, 0.0, Wh};
+    vx = cx[j]; vy = cy[j];
+  }
+
+  // ---------------------------------------------------------------------------------------
+  // Stage loads: x_k, u_k, x_{k+1}, lam_k, lam_{k+1}, s_k, z_k, uprox_k and the record rows.
+  // ---------------------------------------------------------------------------------------
+  CMPC_DEV void load_stage(int k, bool with_mult) {
+    for (int i = lane; i < NXA; i += 64) {
+      L(D::oXK + i) = gx[(size_t)k * NXA + i];
+      L(D::oXN1 + i) = (k < N) ? gx[(size_t)(k + 1) * NXA + i] : 0.0;
+      if (with_mult) {
+        L(D::oLAMK + i) = glam[(size_t)k * NXA + i];
+        L(D::oLAMN + i) = (k < N) ? glam[(size_t)(k + 1) * NXA + i] : 0.0;
+      }
+    }
+    for (int i = lane; i < NU; i += 64) {
+      L(D::oUK + i) = (k < N) ? gu[(size_t)k * NU + i] : 0.0;
+      L(D::oUPX + i) = (k < N) ? gupx[(size_t)k * NU + i] : 0.0;
+    }
+    if (with_mult)
+      for (int i = lane; i < NI; i += 64) {
+        L(D::oSK + i) = gsl[(size_t)k * NI + i];
+        L(D::oZK + i) = gz[(size_t)k * NI + i];
+      }
+    if (lane < 19) {
+      L(D::oSR + lane) = (k < N) ? rec[24 + 19 * k + lane] : 0.0;
+      L(D::oSRP + lane) = (k >= 1) ? rec[24 + 19 * (k - 1) + lane] : 0.0;
+    }
+    if (lane >= 32 && lane < 56) L(D::oHDR + lane - 32) = rec[lane - 32];
+    CMPC_SYNC();
+  }
+
+  // ---------------------------------------------------------------------------------------
+  // Per-vertex geometry, sums, dynamics value b = F(x,u) - x_{k+1}, GH rows.  (k < N)
+  // reference centroidal_dynamic :371-461
+  // MISC: [0..5] Fs[f][a], [6..8] tau, [9..11] pi, [12..20] SF = sum_f gamma_f sum_j skew(f_j),
+  //       [21..26] SFf[f][...] unused, [30..31] psi-psi curvature per foot,
+  //       [32..34] z1, [35..37] z2, [38..40] un, [41..43] gz1, [44..46] gz2, [47..49] V, [50] lyap val
+  // ---------------------------------------------------------------------------------------
+  CMPC_DEV void stage_geometry(int k) {
+    const double d = sp.delta, m = L(D::oHDR + 20);
+    if (lane < NF) {
+      const int f = lane / NV, j = lane % NV;
+      const double yaw = L(D::oXK + 12 + 4 * f);
+      const double cs = cos(yaw), sn = sin(yaw);
+      double vx, vy; vert_local(j, vx, vy);
+      const double rvx = cs * vx - sn * vy, rvy = sn * vx + cs * vy;
+      L(D::oVRV + 3 * lane + 0) = rvx; L(D::oVRV + 3 * lane + 1) = rvy; L(D::oVRV + 3 * lane + 2) = 0.0;
+      L(D::oVDV + 3 * lane + 0) = -sn * vx - cs * vy; L(D::oVDV + 3 * lane + 1) = cs * vx - sn * vy;
+      L(D::oVDV + 3 * lane + 2) = 0.0;
+      L(D::oVR + 3 * lane + 0) = L(D::oXK + 13 + 4 * f + 0) + rvx - L(D::oXK + 0);
+      L(D::oVR + 3 * lane + 1) = L(D::oXK + 13 + 4 * f + 1) + rvy - L(D::oXK + 1);
+      L(D::oVR + 3 * lane + 2) = L(D::oXK + 13 + 4 * f + 2) - L(D::oXK + 2);
+    }
+#ifdef CMPC_NO_DYN_CURV
+    if (lane >= 32 && lane < 35) L(D::oMISC + 9 + lane - 32) = 0.0;
+#else
+    if (lane >= 32 && lane < 35) L(D::oMISC + 9 + lane - 32) = d * L(D::oLAMN + 6 + lane - 32);   // pi
+#endif
+    CMPC_SYNC();
+    if (lane < 3) {
+      const int a = lane, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+      double tau = 0;
+      for (int f = 0; f < 2; ++f) {
+        const double g = L(D::oSR + 17 + f);
+        double fs = 0, t = 0;
+        for (int j = 0; j < NV; ++j) {
+          const int v = f * NV + j;
+          fs += L(D::oUK + 3 * v + a);
+          t += L(D::oVR + 3 * v + a1) * L(D::oUK + 3 * v + a2) - L(D::oVR + 3 * v + a2) * L(D::oUK + 3 * v + a1);
+        }
+        L(D::oMISC + 3 * f + a) = fs;
+        tau += g * t;
+      }
+      L(D::oMISC + 6 + a) = tau;
+    }
+    if (lane >= 32 && lane < 34) {           // psi-psi curvature of foot f:  gamma_f sum_j pi . ((R''v_j) x f_j)
+      const int f = lane - 32;
+      const double g = L(D::oSR + 17 + f);
+      const double p0 = L(D::oMISC + 9), p1 = L(D::oMISC + 10), p2 = L(D::oMISC + 11);
+      double acc = 0;
+      for (int j = 0; j < NV; ++j) {
+        const int v = f * NV + j;
+        const double ax = -L(D::oVRV + 3 * v), ay = -L(D::oVRV + 3 * v + 1);
+        const double fx = L(D::oUK + 3 * v), fy = L(D::oUK + 3 * v + 1), fz = L(D::oUK + 3 * v + 2);
+        acc += p0 * (ay * fz) + p1 * (-ax * fz) + p2 * (ax * fy - ay * fx);
+      }
+      L(D::oMISC + 30 + f) = g * acc;
+    }
+    CMPC_SYNC();
+    // GH[a][col]: rows 6..8 of [B A] minus identity
+    for (int col = lane; col < NZ; col += 64) {
+      double g0 = 0, g1 = 0, g2 = 0;
+      if (col < 6 * NV) {                    // force component: d*gamma*skew(r)[.][a]
+        const int v = col / 3, a = col % 3, f = v / NV;
+        const double g = d * L(D::oSR + 17 + f);
+        const double rx = L(D::oVR + 3 * v), ry = L(D::oVR + 3 * v + 1), rz = L(D::oVR + 3 * v + 2);
+        // column a of skew(r) = r x e_a, written branch-free
+        const double e0 = (a == 0) ? 1.0 : 0.0, e1 = (a == 1) ? 1.0 : 0.0, e2 = (a == 2) ? 1.0 : 0.0;
+        g0 = g * (ry * e2 - rz * e1); g1 = g * (rz * e0 - rx * e2); g2 = g * (rx * e1 - ry * e0);
+      } else if (col >= NU) {
+        const int s = col - NU;
+        if (s < 3 || (s >= 13 && s < 16) || (s >= 17 && s < 20)) {
+          // c_a: +d*sum_f gamma_f sum_j skew(f_j)[.][a];  p_{f,a}: -d*gamma_f sum_j skew(f_j)[.][a]
+          const int a = (s < 3) ? s : (s - 13) % 4;
+          double F0 = 0, F1 = 0, F2 = 0;
+          for (int f = 0; f < 2; ++f) {
+            if (s >= 13 && f != (s >= 17)) continue;
+            const double g = L(D::oSR + 17 + f);
+            F0 += g * L(D::oMISC + 3 * f); F1 += g * L(D::oMISC + 3 * f + 1); F2 += g * L(D::oMISC + 3 * f + 2);
+          }
+          const double e0 = (a == 0) ? 1.0 : 0.0, e1 = (a == 1) ? 1.0 : 0.0, e2 = (a == 2) ? 1.0 : 0.0;
+          const double sg = (s < 3) ? d : -d;
+          g0 = sg * (F1 * e2 - F2 * e1); g1 = sg * (F2 * e0 - F0 * e2); g2 = sg * (F0 * e1 - F1 * e0);
+        } else if (s == 12 || s == 16) {     // yaw: d*gamma_f sum_j (R'v_j) x f_j
+          const int f = (s == 16);
+          const double g = d * L(D::oSR + 17 + f);
+          for (int j = 0; j < NV; ++j) {
+            const int v = f * NV + j;
+            const double ax = L(D::oVDV + 3 * v), ay = L(D::oVDV + 3 * v + 1);
+            const double fx = L(D::oUK + 3 * v), fy = L(D::oUK + 3 * v + 1), fz = L(D::oUK + 3 * v + 2);
+            g0 += ay * fz; g1 += -ax * fz; g2 += ax * fy - ay * fx;
+          }
+          g0 *= g; g1 *= g; g2 *= g;
+        }
+      }
+      L(D::oGH + col) = g0; L(D::oGH + NZ + col) = g1; L(D::oGH + 2 * NZ + col) = g2;
+    }
+    // b = F(x,u) - x_{k+1}
+    if (lane < NXA) {
+      const int q = lane;
+      double xn;
+      const double *x = &L(D::oXK), *u = &L(D::oUK), *sr = &L(D::oSR);
+      if (q < 3) xn = x[q] + d * x[3 + q];
+      else if (q < 6) {
+        const int a = q - 3;
+        xn = x[q] + d * (((a == 2) ? -sp.g : 0.0) + (sr[17] * L(D::oMISC + a) + sr[18] * L(D::oMISC + 3 + a)) / m);
+      } else if (q < 9) xn = x[q] + d * L(D::oMISC + 6 + q - 6);
+      else if (q < 12) { const int a = q - 9; xn = x[q] + d / m * (sp.k1 * (x[a] - sr[a]) + x[3 + a] - sr[3 + a]); }
+      else if (q == 12) xn = x[12] + d * (1 - sr[17]) * u[6 * NV + 6];
+      else if (q < 16) xn = x[q] + d * (1 - sr[17]) * u[6 * NV + q - 13];
+      else if (q == 16) xn = x[16] + d * (1 - sr[18]) * u[6 * NV + 7];
+      else if (q < 20) xn = x[q] + d * (1 - sr[18]) * u[6 * NV + 3 + q - 17];
+      else xn = u[3 * (q - 20) + 2];
+      L(D::oBV + q) = xn - L(D::oXN1 + q);
+    }
+    CMPC_SYNC();
+  }
+
+  // Column list of [B A] for this lane's column (lane < NZ): id, 3 h-rows, 2 specials.
+  CMPC_DEV void build_list(const double *gh, double gl, double gr, double m) {
+    const double d = sp.delta;
+    for (int n = 0; n < 6; ++n) { lr[n] = 0; lg[n] = 0.0; }
+    if (lane >= NZ) return;
+    const int col = lane;
+    lr[1] = 6; lr[2] = 7; lr[3] = 8;
+    lg[1] = gh[col]; lg[2] = gh[NZ + col]; lg[3] = gh[2 * NZ + col];
+    if (col < 6 * NV) {
+      const int v = col / 3, a = col % 3, f = v / NV;
+      lr[4] = 3 + a; lg[4] = d * (f ? gr : gl) / m;
+      if (a == 2) { lr[5] = 20 + v; lg[5] = 1.0; }
+    } else if (col < 6 * NV + 6) {
+      const int f = (col - 6 * NV) / 3, a = (col - 6 * NV) % 3;
+      lr[4] = 13 + 4 * f + a; lg[4] = d * (1 - (f ? gr : gl));
+    } else if (col < NU) {
+      const int f = col - 6 * NV - 6;
+      lr[4] = 12 + 4 * f; lg[4] = d * (1 - (f ? gr : gl));
+    } else {
+      const int s = col - NU;
+      if (s < CMPC_NX) { lr[0] = s; lg[0] = 1.0; }
+      if (s < 3) { lr[4] = 9 + s; lg[4] = d * sp.k1 / m; }
+      else if (s < 6) { lr[4] = s - 3; lg[4] = d; lr[5] = 9 + s - 3; lg[5] = d / m; }
+    }
+  }
+
+  // ---------------------------------------------------------------------------------------
+  // Inequality rows g (<= 0), Lyapunov gradient AL, activity.  reference :193-271
+  // ---------------------------------------------------------------------------------------
+  CMPC_DEV void stage_ineq(int k, double x0n2) {
+    const double m = L(D::oHDR + 20), muf = L(D::oHDR + 21), rl = sp.relax;
+    const double d = sp.delta, k1 = sp.k1, k2 = sp.k2;
+    if (k < N && lane < 3) {
+      const int a = lane;
+      const double *x = &L(D::oXK), *sr = &L(D::oSR);
+      const double grav = (a == 2) ? -sp.g : 0.0;
+      const double V = (sr[17] * L(D::oMISC + a) + sr[18] * L(D::oMISC + 3 + a)) / m;
+      const double z1 = x[a] + d * x[3 + a] - sr[a];
+      const double z2 = k1 * z1 + x[3 + a] + d * (grav + V) - sr[3 + a];
+      const double un = -(k1 + k2) * z2 + k1 * k1 * z1 - grav + sr[6 + a] - x[9 + a] / m;
+      L(D::oMISC + 32 + a) = z1; L(D::oMISC + 35 + a) = z2; L(D::oMISC + 38 + a) = un;
+      L(D::oMISC + 41 + a) = -2 * k1 * z1 + z2 - k1 * k1 * z2;
+      L(D::oMISC + 44 + a) = -2 * k2 * z2 + z1 + (V - un) + (k1 + k2) * z2;
+      L(D::oMISC + 47 + a) = V;
+      L(D::oRED + a) = -k1 * z1 * z1 - k2 * z2 * z2 + z1 * z2 + z2 * (V - un);
+    }
+    CMPC_SYNC();
+    // Lyapunov gradient over z = (u, x)
+    for (int col = lane; col < NZ; col += 64) {
+      double v = 0.0;
+      if (k < N) {
+        if (col < 6 * NV) {
+          const int a = col % 3, f = (col / 3) / NV;
+          v = L(D::oSR + 17 + f) / m * (d * L(D::oMISC + 44 + a) + L(D::oMISC + 35 + a));
+        } else if (col >= NU && k >= 1) {
+          const int s = col - NU;
+          if (s < 3) v = L(D::oMISC + 41 + s) + k1 * L(D::oMISC + 44 + s);
+          else if (s < 6) v = d * L(D::oMISC + 41 + s - 3) + (k1 * d + 1) * L(D::oMISC + 44 + s - 3);
+          else if (s >= 9 && s < 12) v = L(D::oMISC + 35 + s - 9) / m;
+        }
+      }
+      L(D::oAL + col) = v;
+    }
+    for (int r = lane; r < NI; r += 64) {
+      double g = 0.0; bool act = false;
+      if (r == R_LYAP) { if (k < N) { g = L(D::oRED) + L(D::oRED + 1) + L(D::oRED + 2) - rl; act = true; } }
+      else if (r == R_CZ) { if (k >= 1 && k < N) { g = L(D::oXK + 2) - sp.cz_max - rl; act = true; } }
+      else if (r == R_HWC) {
+        if (k == 1) { g = L(D::oXK + 6) * L(D::oXK + 6) + L(D::oXK + 7) * L(D::oXK + 7) + L(D::oXK + 8) * L(D::oXK + 8) - x0n2 - rl; act = true; }
+      } else if (r < R_FRIC) {
+        const int q = r - R_BOX, f = q / 6, a = (q % 6) / 2, sgn = (q & 1) ? -1 : 1;
+        if (k >= 1) {
+          const double gg = gam_k(k, f);
+          if (gg != 0.0) {
+            const double dd = (L(D::oXK + 13 + 4 * f + a) - L(D::oSRP + 9 + 3 * f + a)) * gg;
+            g = sgn * dd - sp.box[a] - rl; act = true;
+          }
+        }
+      } else {
+        const int q = r - R_FRIC, v = q / 5, t = q % 5, f = v / NV;
+        if (k < N) {
+          const double gg = L(D::oSR + 17 + f);
+          if (gg != 0.0) {
+            const double fx = L(D::oUK + 3 * v), fy = L(D::oUK + 3 * v + 1), fz = L(D::oUK + 3 * v + 2);
+            double e;
+            if (t == 0) e = fx - muf * fz; else if (t == 1) e = -fx - muf * fz;
+            else if (t == 2) e = fy - muf * fz; else if (t == 3) e = -fy - muf * fz; else e = -fz;
+            g = gg * e - rl; act = true;
+          }
+        }
+      }
+      L(D::oGK + r) = g;
+      L(D::oW2 + r) = act ? 1.0 : 0.0;     // activity flag (overwritten with 1/s later)
+    }
+    CMPC_SYNC();
+  }
+
+  // (Jg' w)[col] for row weights w (zero on inactive rows).
+  CMPC_DEV double jgt(int k, int col, const double *w) const {
+    const double muf = L(D::oHDR + 21);
+    double v = L(D::oAL + col) * w[R_LYAP];
+    if (col < 6 * NV) {
+      const int vtx = col / 3, a = col % 3, f = vtx / NV;
+      const double gg = (k < N) ? L(D::oSR + 17 + f) : 0.0;
+      const double *wr = w + R_FRIC + 5 * vtx;
+      if (a == 0) v += gg * (wr[0] - wr[1]);
+      else if (a == 1) v += gg * (wr[2] - wr[3]);
+      else v += -gg * muf * (wr[0] + wr[1] + wr[2] + wr[3]) - gg * wr[4];
+    } else if (col >= NU) {
+      const int s = col - NU;
+      if (s == 2) v += w[R_CZ];
+      else if (s >= 6 && s < 9) v += 2.0 * L(D::oXK + s) * w[R_HWC];
+      else if ((s >= 13 && s < 16) || (s >= 17 && s < 20)) {
+        const int f = (s >= 17), a = (s - 13) % 4;
+        const double gg = (k >= 1) ? gam_k(k, f) : 0.0;
+        v += gg * (w[R_BOX + 6 * f + 2 * a] - w[R_BOX + 6 * f + 2 * a + 1]);
+      }
+    }
+    return v;
+  }
+
+  // Objective gradient entry for column col.  reference :275-353
+  CMPC_DEV double cost_grad(int k, int col) const {
+    const double *x = &L(D::oXK), *u = &L(D::oUK);
+    double v = 0.0;
+    if (col < NU) {
+      if (k >= N) return 0.0;
+      v = sp.prox * (u[col] - L(D::oUPX + col));
+      if (col < 6 * NV) {
+        const int vtx = col / 3, a = col % 3, f = vtx / NV;
+        const double g1 = L(D::oSR + 17 + f);
+        const double a_ = g1 * g1 / NV, coef = NV * a_ * a_ - 2 * a_;
+        const double wa = sp.w_force * g1, wb = sp.w_force * (1 - g1);
+        v += wa * (2 * coef * L(D::oMISC + 3 * f + a) + 2 * u[col]) + wb * 2 * u[col];
+        if (a == 2 && k >= 1) v += 2 * sp.w_rate * gam_km1(f) * (u[col] - x[CMPC_NX + vtx]);
+      }
+    } else {
+      const int s = col - NU;
+      if (k < 1) return 0.0;
+      const double *pr = &L(D::oSRP);
+      if (s < 3) v = 2 * ((s == 2) ? w_cz(k - 1) : sp.w_cxy) * (x[s] - pr[s]);
+      else if (s >= 6 && s < 9) v = (k < N) ? 2 * sp.w_hw * x[s] : 0.0;
+      else if (s == 12 || s == 16) { const int f = (s == 16); const double g = gam_k(k, f); v = 2 * sp.w_foot * g * g * (x[s] - pr[15 + f]); }
+      else if ((s >= 13 && s < 16) || (s >= 17 && s < 20)) {
+        const int f = (s >= 17), a = (s - 13) % 4; const double g = gam_k(k, f);
+        v = 2 * sp.w_foot * g * g * (x[s] - pr[9 + 3 * f + a]);
+      } else if (s >= CMPC_NX && k < N) {
+        const int vtx = s - CMPC_NX, f = vtx / NV;
+        v = -2 * sp.w_rate * gam_km1(f) * (u[3 * vtx + 2] - x[s]);
+      }
+    }
+    return v;
+  }
+
+  // ---------------------------------------------------------------------------------------
+  // Row `lane` of the Lagrangian Hessian + barrier terms into the packed lower triangle M.
+  // ---------------------------------------------------------------------------------------
+  CMPC_DEV void build_H(int k, double reg) {
+    if (lane >= NZ) return;
+    const int i = lane;
+    double *row = &L(D::oM + tri(i));
+    for (int j = 0; j <= i; ++j) row[j] = 0.0;
+    const double m = L(D::oHDR + 20), muf = L(D::oHDR + 21);
+    const double *x = &L(D::oXK);
+    const double *sig = &L(D::oW0);
+    const double sigL = sig[R_LYAP], zL = L(D::oZK + R_LYAP) * ((k < N) ? 1.0 : 0.0);
+    const double d = sp.delta, k1 = sp.k1;
+    // Lyapunov quadratic-form coefficients hq (4x4 over c, v, theta, V)
+    const double a1[4] = {1, d, 0, 0}, a2[4] = {k1, k1 * d + 1, 0, d};
+    const double aS[4] = {0, 0, 1.0 / m, 1};
+    // type/axis/scale of an index for the Lyapunov terms: t = 0 c, 1 v, 2 theta, 3 V(force), -1 none
+    auto lyt = [&](int idx, int &t, int &a, double &sc) {
+      t = -1; a = 0; sc = 0.0;
+      if (idx < 6 * NV) { t = 3; a = idx % 3; sc = L(D::oSR + 17 + (idx / 3) / NV) / m; }
+      else if (idx >= NU && k >= 1) {
+        const int s = idx - NU;
+        if (s < 3) { t = 0; a = s; sc = 1.0; } else if (s < 6) { t = 1; a = s - 3; sc = 1.0; }
+        else if (s >= 9 && s < 12) { t = 2; a = s - 9; sc = 1.0; }
+      }
+    };
+    auto hq = [&](int p, int q) {
+      return -2 * k1 * a1[p] * a1[q] + 2 * k1 * a2[p] * a2[q] + (1 - k1 * k1) * (a1[p] * a2[q] + a2[p] * a1[q]) +
+             a2[p] * aS[q] + aS[p] * a2[q];
+    };
+    double diag = reg;
+    if (i < NU) {
+      if (k < N) {
+        diag += sp.prox;
+        if (i < 6 * NV) {
+          const int vtx = i / 3, a = i % 3, f = vtx / NV, jv = vtx % NV;
+          const double g1 = L(D::oSR + 17 + f);
+          const double a_ = g1 * g1 / NV, coef = NV * a_ * a_ - 2 * a_;
+          const double wa = sp.w_force * g1, wb = sp.w_force * (1 - g1);
+          diag += 2 * wa + 2 * wb + 2 * wa * coef;
+          for (int l = 0; l < jv; ++l) row[3 * (f * NV + l) + a] += 2 * wa * coef;   // mean-force coupling
+          if (a == 2 && k >= 1) diag += 2 * sp.w_rate * gam_km1(f);
+          // friction-cone barrier block of this vertex
+          const double *sr5 = sig + R_FRIC + 5 * vtx;
+          const double g2 = g1 * g1;
+          if (a == 0) diag += g2 * (sr5[0] + sr5[1]);
+          else if (a == 1) diag += g2 * (sr5[2] + sr5[3]);
+          else {
+            diag += g2 * (muf * muf * (sr5[0] + sr5[1] + sr5[2] + sr5[3]) + sr5[4]);
+            row[3 * vtx + 0] += -g2 * muf * (sr5[0] - sr5[1]);
+            row[3 * vtx + 1] += -g2 * muf * (sr5[2] - sr5[3]);
+          }
+        }
+      } else diag += 1.0;                              // no inputs at the terminal node
+    } else {
+      const int s = i - NU;
+      if (k >= 1) {
+        if (s < 3) { diag += 2 * ((s == 2) ? w_cz(k - 1) : sp.w_cxy); if (s == 2) diag += sig[R_CZ]; }
+        else if (s >= 6 && s < 9) {
+          if (k < N) diag += 2 * sp.w_hw;
+          if (k == 1) {
+            diag += 2 * L(D::oZK + R_HWC) + 4 * sig[R_HWC] * x[s] * x[s];
+            for (int b = 6; b < s; ++b) row[NU + b] += 4 * sig[R_HWC] * x[s] * x[b];
+          }
+        } else if (s == 12 || s == 16) { const double g = gam_k(k, s == 16); diag += 2 * sp.w_foot * g * g; }
+        else if ((s >= 13 && s < 16) || (s >= 17 && s < 20)) {
+          const int f = (s >= 17), a = (s - 13) % 4; const double g = gam_k(k, f);
+          diag += 2 * sp.w_foot * g * g + g * g * (sig[R_BOX + 6 * f + 2 * a] + sig[R_BOX + 6 * f + 2 * a + 1]);
+        } else if (s >= CMPC_NX && k < N) {
+          const int vtx = s - CMPC_NX, f = vtx / NV;
+          const double wr = sp.w_rate * gam_km1(f);
+          diag += 2 * wr;
+          row[3 * vtx + 2] += -2 * wr;
+        }
+      }
+      if (k < N) {                                      // dynamics curvature  pi . d2 tau
+        const double p0 = L(D::oMISC + 9), p1 = L(D::oMISC + 10), p2 = L(D::oMISC + 11);
+        auto Sp = [&](int a, int b) -> double {       // skew(pi)[a][b]
+          if (a == b) return 0.0;
+          if (a == 0) return (b == 1) ? -p2 : p1;
+          if (a == 1) return (b == 0) ? p2 : -p0;
+          return (b == 0) ? -p1 : p0;
+        };
+        if (s < 3) {
+          for (int v = 0; v < NF; ++v) {
+            const double g = L(D::oSR + 17 + v / NV);
+            for (int a = 0; a < 3; ++a) row[3 * v + a] += -g * Sp(a, s);
+          }
+        } else if ((s >= 13 && s < 16) || (s >= 17 && s < 20)) {
+          const int f = (s >= 17), b = (s - 13) % 4; const double g = L(D::oSR + 17 + f);
+          for (int j = 0; j < NV; ++j) for (int a = 0; a < 3; ++a) row[3 * (f * NV + j) + a] += g * Sp(a, b);
+        } else if (s == 12 || s == 16) {
+          const int f = (s == 16); const double g = L(D::oSR + 17 + f);
+          for (int j = 0; j < NV; ++j) {
+            const int v = f * NV + j;
+            const double dx_ = L(D::oVDV + 3 * v), dy_ = L(D::oVDV + 3 * v + 1);
+            for (int a = 0; a < 3; ++a) row[3 * v + a] += g * (Sp(a, 0) * dx_ + Sp(a, 1) * dy_);
+          }
+          diag += L(D::oMISC + 30 + f);
+        }
+      }
+    }
+    // Lyapunov: barrier rank-1 + multiplier-weighted constant Hessian
+    if (k < N) {
+      int ti, ai; double sci;
+      lyt(i, ti, ai, sci);
+      if (ti >= 0) {
+        const double ali = L(D::oAL + i);
+        const double sA = sigL * ali;
+        const double hV = zL * hq(ti, 3) * sci / m;     // against a force column of the same axis
+        const double gl_ = L(D::oSR + 17), gr_ = L(D::oSR + 18);
+        const int jf = (i < 6 * NV) ? i : 6 * NV - 1;   // force columns j <= i
+        for (int j = 0; j <= jf; ++j) {
+          double v = sA * L(D::oAL + j);
+          if (j % 3 == ai) v += hV * ((j < 3 * NV) ? gl_ : gr_);
+          if (j == i) diag += v; else row[j] += v;
+        }
+        if (i >= NU) {                                  // state columns c, v, theta (k >= 1 here)
+          const int so[3] = {0, 3, 9};
+          for (int t = 0; t < 3; ++t)
+            for (int a = 0; a < 3; ++a) {
+              const int j = NU + so[t] + a;
+              if (j > i) continue;
+              double v = sA * L(D::oAL + j);
+              if (a == ai) v += zL * hq(ti, t) * sci;
+              if (j == i) diag += v; else row[j] += v;
+            }
+        }
+      }
+    }
+    row[i] += diag;
+  }
+
+  // M += [B A]' P [B A]  (lower triangle, row owner), using T = P [B A] staged by column halves.
+  CMPC_DEV void add_GtPG() {
+    for (int half = 0; half < 2; ++half) {
+      const int c0 = half * D::TH, c1 = (c0 + D::TH < NZ) ? c0 + D::TH : NZ;
+      if (lane >= c0 && lane < c1) {
+#pragma unroll 4
+        for (int q = 0; q < NXA; ++q) {
+          double a = 0.0;
+#pragma unroll
+          for (int n = 0; n < 6; ++n) a += lg[n] * L(D::oP + q * D::PS + lr[n]);
+          L(D::oT + q * D::TS + (lane - c0)) = a;
+        }
+      }
+      CMPC_SYNC();
+      if (lane < NZ) {
+        const int iend = (lane < c1 - 1) ? lane : c1 - 1;
+        double *row = &L(D::oM + tri(lane));
+#pragma unroll 4
+        for (int i = c0; i <= iend; ++i) {
+          double a = 0.0;
+#pragma unroll
+          for (int n = 0; n < 6; ++n) a += lg[n] * L(D::oT + lr[n] * D::TS + (i - c0));
+          row[i] += a;
+        }
+      }
+      CMPC_SYNC();
+    }
+  }
+
+  // Cholesky of the input block, Ls, Schur complement.  Returns false on a non-positive pivot.
+  CMPC_DEV bool factor_stage(int k) {
+    double *M = &L(D::oM);
+    for (int j = 0; j < NU; ++j) {
+      double acc = 0.0;
+      if (lane >= j && lane < NZ) {
+        const double *ri = M + tri(lane), *rj = M + tri(j);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int q = 0;
+        for (; q + 4 <= j; q += 4) {             // independent partial sums: LDS reads batch up
+          a0 += ri[q] * rj[q]; a1 += ri[q + 1] * rj[q + 1];
+          a2 += ri[q + 2] * rj[q + 2]; a3 += ri[q + 3] * rj[q + 3];
+        }
+        for (; q < j; ++q) a0 += ri[q] * rj[q];
+        acc = ri[j] - ((a0 + a1) + (a2 + a3));
+        if (lane == j) L(D::oRED) = acc;
+      }
+      CMPC_SYNC();
+      const double piv = L(D::oRED);
+      if (!(piv > 1e-14)) return false;
+      if (lane >= j && lane < NZ) {
+        const double dj = sqrt(piv);
+        M[tri(lane) + j] = (lane == j) ? dj : acc / dj;
+      }
+      CMPC_SYNC();
+    }
+    if (k == 0) return true;                 // x_0 is data: no cost-to-go needed
+    // P_k = M_xx - Ls Ls'   (row owner i, all columns; split the q-range over the two lane halves)
+    // lanes 0..31 subtract their half of the q-sum in place (columns >= NU of their own row, which
+    // nobody reads here); lanes 32..63 park the other half in the T region (NXA*PS <= NXA*TS).
+    static_assert(NXA * D::PS <= NXA * D::TS, "T region too small for the Schur partials");
+    {
+      const int hsel = lane >> 5;
+      const int q0 = hsel ? NU / 2 : 0;
+      static_assert((NU / 2) % 4 == 0, "q-range split assumes NU % 8 == 0");
+      for (int ii = (lane & 31); ii < NXA; ii += 32) {
+        double *ri = M + tri(NU + ii);
+        for (int c = 0; c <= ii; ++c) {
+          const double *rc = M + tri(NU + c);
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+          for (int q = 0; q < NU / 2; q += 4) {
+            a0 += ri[q0 + q] * rc[q0 + q]; a1 += ri[q0 + q + 1] * rc[q0 + q + 1];
+            a2 += ri[q0 + q + 2] * rc[q0 + q + 2]; a3 += ri[q0 + q + 3] * rc[q0 + q + 3];
+          }
+          const double a = (a0 + a1) + (a2 + a3);
+          if (hsel) L(D::oT + ii * D::PS + c) = a; else ri[NU + c] -= a;
+        }
+      }
+    }
+    CMPC_SYNC();
+    for (int e = lane; e < NXA * NXA; e += 64) {
+      const int i = e / NXA, c = e % NXA;
+      const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
+      L(D::oP + i * D::PS + c) = M[tri(NU + hi) + NU + lo] - L(D::oT + hi * D::PS + lo);
+    }
+    CMPC_SYNC();
+    return true;
+  }
+
+  // Store factor blocks of stage k to the global slab (unit stride over lanes).
+  CMPC_DEV void store_factors(int k) {
+    double *st = stage(k);
+    const double *M = &L(D::oM);
+    if (k < N) {
+      for (int e = lane; e < NU * NU; e += 64) {
+        const int i = e / NU, j = e % NU;
+        st[D::gLAM + e] = (j <= i) ? M[tri(i) + j] : 0.0;
+      }
+      for (int e = lane; e < NXA * NU; e += 64) {
+        const int i = e / NU, j = e % NU;
+        st[D::gLS + e] = M[tri(NU + i) + j];
+      }
+    }
+    if (k >= 1)
+      for (int e = lane; e < NXA * NXA; e += 64) st[D::gPK + e] = L(D::oP + (e / NXA) * D::PS + (e % NXA));
+  }
+
+  struct Err { double e_d, e_p, e_c, e_cmu, sum_mult; int n_mult; };
+
+  // ---------------------------------------------------------------------------------------
+  // Matrix sweep: evaluate + factorise every stage backwards.  Returns false on wrong inertia.
+  // Accumulates the KKT error measures (per lane; reduced by the caller).
+  // ---------------------------------------------------------------------------------------
+  CMPC_DEV bool matrix_sweep(double mu, double reg, double x0n2, Err &er) {
+    er.e_d = er.e_p = er.e_c = er.e_cmu = er.sum_mult = 0.0; er.n_mult = 0;
+    for (int k = N; k >= 0; --k) {
+      load_stage(k, true);
+      if (k < N) {
+        stage_geometry(k);
+        if (dbg_on && ka.dbg && k == 5) {   // diagnostic: geometry of stage 5
+          double *o = ka.dbg + 60000;
+          for (int e = lane; e < 3 * NF; e += 64) o[e] = L(D::oVR + e);
+          o[24 + lane] = L(D::oMISC + lane);
+          for (int e = lane; e < NXA; e += 64) { o[88 + e] = L(D::oXK + e); o[148 + e] = L(D::oBV + e); o[176 + e] = L(D::oXN1 + e); }
+          for (int e = lane; e < NU; e += 64) o[116 + e] = L(D::oUK + e);
+          for (int e = lane; e < 3 * NZ; e += 64) o[210 + e] = L(D::oGH + e);
+        }
+      } else {
+        for (int c = lane; c < 3 * NZ; c += 64) L(D::oGH + c) = 0.0;
+        if (lane < NXA) L(D::oBV + lane) = 0.0;
+        CMPC_SYNC();
+      }
+      stage_ineq(k, x0n2);
+      // barrier weights (W2 holds the activity flag on entry)
+      for (int r = lane; r < NI; r += 64) {
+        const bool act = L(D::oW2 + r) != 0.0;
+        const double s = L(D::oSK + r), z = L(D::oZK + r), g = L(D::oGK + r);
+        if (act) {
+          const double sg = z / s;
+          L(D::oW0 + r) = sg; L(D::oW1 + r) = sg * (g + s); L(D::oW2 + r) = 1.0 / s;
+          er.e_p = fmax(er.e_p, fabs(g + s));
+          er.e_c = fmax(er.e_c, fabs(s * z)); er.e_cmu = fmax(er.e_cmu, fabs(s * z - mu));
+          er.sum_mult += fabs(z); er.n_mult += 1;
+        } else {
+          L(D::oW0 + r) = 0.0; L(D::oW1 + r) = 0.0; L(D::oW2 + r) = 0.0; L(D::oZK + r) = 0.0;
+        }
+      }
+      if (k < N && lane < NXA) er.e_p = fmax(er.e_p, fabs(L(D::oBV + lane)));
+      if (k >= 1 && lane < NXA) { er.sum_mult += fabs(L(D::oLAMK + lane)); er.n_mult += 1; }
+      CMPC_SYNC();
+      build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
+      double *st = stage(k);
+      if (lane < NZ) {
+        const int col = lane;
+        const double ho = cost_grad(k, col);
+        double r = ho + jgt(k, col, &L(D::oZK));
+        if (k < N) for (int n = 0; n < 6; ++n) r += lg[n] * L(D::oLAMN + lr[n]);
+        if (col >= NU) r -= L(D::oLAMK + col - NU);
+        const bool is_var = (col < NU) ? (k < N) : (k >= 1);
+        if (is_var) er.e_d = fmax(er.e_d, fabs(r));
+        st[D::gH0 + col] = ho + jgt(k, col, &L(D::oW1));
+        st[D::gH1 + col] = jgt(k, col, &L(D::oW2));
+        st[D::gAL + col] = L(D::oAL + col);
+      }
+      for (int c = lane; c < 3 * NZ; c += 64) st[D::gGH + c] = L(D::oGH + c);
+      for (int r = lane; r < NI; r += 64) st[D::gG + r] = L(D::oGK + r);
+      CMPC_TICK(0);
+      build_H(k, reg);
+      CMPC_SYNC();
+      CMPC_TICK(1);
+      if (k < N) {
+        // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG
+        if (lane < NXA) {
+          double a = 0.0;
+          for (int q = 0; q < NXA; ++q) a += L(D::oP + lane * D::PS + q) * L(D::oBV + q);
+          st[D::gPB + lane] = a;
+          st[D::gB + lane] = L(D::oBV + lane);
+        }
+        add_GtPG();
+        CMPC_TICK(2);
+        if (!factor_stage(k)) return false;
+        CMPC_TICK(3);
+      } else {
+        for (int e = lane; e < NXA * NXA; e += 64) {
+          const int i = e / NXA, c = e % NXA;
+          const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
+          L(D::oP + i * D::PS + c) = L(D::oM + tri(NU + hi) + NU + lo);
+        }
+        CMPC_SYNC();
+      }
+      store_factors(k);
+      CMPC_SYNC();
+      CMPC_TICK(4);
+    }
+    return true;
+  }
+
+  CMPC_DEV double red_max(double v) {
+    L(D::oRED + lane) = v; CMPC_SYNC();
+    double r = L(D::oRED);
+    for (int i = 1; i < 64; ++i) r = fmax(r, L(D::oRED + i));
+    CMPC_SYNC();
+    return r;
+  }
+  CMPC_DEV double red_min(double v) {
+    L(D::oRED + lane) = v; CMPC_SYNC();
+    double r = L(D::oRED);
+    for (int i = 1; i < 64; ++i) r = fmin(r, L(D::oRED + i));
+    CMPC_SYNC();
+    return r;
+  }
+  CMPC_DEV double red_sum(double v) {
+    L(D::oRED + lane) = v; CMPC_SYNC();
+    double r = 0.0;
+    for (int i = 0; i < 64; ++i) r += L(D::oRED + i);
+    CMPC_SYNC();
+    return r;
+  }
+
+  // Copy L (NU x NU) and Ls (NXA x NU) of stage k into LDS (M region, strides LS).
+  CMPC_DEV void load_factors(int k) {
+    const double *st = stage(k);
+    for (int e = lane; e < NU * NU; e += 64) L(D::oM + (e / NU) * D::LS + (e % NU)) = st[D::gLAM + e];
+    for (int e = lane; e < NXA * NU; e += 64) L(D::oM + (NU + e / NU) * D::LS + (e % NU)) = st[D::gLS + e];
+    for (int c = lane; c < 3 * NZ; c += 64) L(D::oGH + c) = st[D::gGH + c];
+    if (lane < 19) L(D::oSR + lane) = rec[24 + 19 * k + lane];
+    CMPC_SYNC();
+  }
+
+  // ---------------------------------------------------------------------------------------
+  // Vector sweeps: l_k, p_k backwards, then du, dx, lam+ forwards.
+  // ---------------------------------------------------------------------------------------
+  CMPC_DEV void vector_sweeps(double mu) {
+    const double m = rec[20];
+    {
+      const double *st = stage(N);
+      if (lane < NXA) {
+        const double p = st[D::gH0 + NU + lane] + mu * st[D::gH1 + NU + lane];
+        L(D::oPC + lane) = p;
+        stage(N)[D::gPV + lane] = p;
+      }
+      CMPC_SYNC();
+    }
+    for (int k = N - 1; k >= 0; --k) {
+      load_factors(k);
+      double *st = stage(k);
+      build_list(&L(D::oGH), L(D::oSR + 17), L(D::oSR + 18), m);
+      if (lane < NXA) L(D::oXN1 + lane) = L(D::oPC + lane) + st[D::gPB + lane];
+      CMPC_SYNC();
+      if (lane < NZ) {
+        double a = st[D::gH0 + lane] + mu * st[D::gH1 + lane];
+        for (int n = 0; n < 6; ++n) a += lg[n] * L(D::oXN1 + lr[n]);
+        L(D::oTV + lane) = a;
+      }
+      CMPC_SYNC();
+      // l = L^-1 m_u  (column-oriented forward substitution)
+      for (int j = 0; j < NU; ++j) {
+        if (lane == j) L(D::oTV + j) = L(D::oTV + j) / L(D::oM + j * D::LS + j);
+        CMPC_SYNC();
+        if (lane > j && lane < NU) L(D::oTV + lane) -= L(D::oM + lane * D::LS + j) * L(D::oTV + j);
+        CMPC_SYNC();
+      }
+      if (lane < NU) st[D::gL + lane] = L(D::oTV + lane);
+      if (lane < NXA) {
+        double a = L(D::oTV + NU + lane);
+        for (int q = 0; q < NU; ++q) a -= L(D::oM + (NU + lane) * D::LS + q) * L(D::oTV + q);
+        L(D::oPC + lane) = a;
+        st[D::gPV + lane] = a;
+      }
+      CMPC_SYNC();
+    }
+    CMPC_TICK(5);
+    // forward
+    if (lane < NXA) { L(D::oXK + lane) = 0.0; gdx[lane] = 0.0; }
+    CMPC_SYNC();
+    for (int k = 0; k < N; ++k) {
+      load_factors(k);
+      const double *st = stage(k);
+      if (lane < NU) {
+        double a = st[D::gL + lane];
+        for (int i = 0; i < NXA; ++i) a += L(D::oM + (NU + i) * D::LS + lane) * L(D::oXK + i);
+        L(D::oTV + lane) = -a;
+      }
+      CMPC_SYNC();
+      for (int j = NU - 1; j >= 0; --j) {      // L' du = t
+        if (lane == j) L(D::oTV + j) = L(D::oTV + j) / L(D::oM + j * D::LS + j);
+        CMPC_SYNC();
+        if (lane < j) L(D::oTV + lane) -= L(D::oM + j * D::LS + lane) * L(D::oTV + j);
+        CMPC_SYNC();
+      }
+      if (lane < NU) { gdu[(size_t)k * NU + lane] = L(D::oTV + lane); L(D::oUK + lane) = L(D::oTV + lane); }
+      CMPC_SYNC();
+      // dx+ = b + [B A] (du, dx)
+      if (lane < NXA) {
+        const int q = lane;
+        const double d = sp.delta, gl = L(D::oSR + 17), gr = L(D::oSR + 18);
+        const double *dx = &L(D::oXK), *du = &L(D::oUK);
+        double a = st[D::gB + q];
+        if (q < 3) a += dx[q] + d * dx[3 + q];
+        else if (q < 6) {
+          double fs = 0.0;
+          for (int v = 0; v < NF; ++v) fs += ((v < NV) ? gl : gr) * du[3 * v + q - 3];
+          a += dx[q] + d / m * fs;
+        } else if (q < 9) {
+          a += dx[q];
+          const double *gh = &L(D::oGH + (q - 6) * NZ);
+          for (int c = 0; c < NU; ++c) a += gh[c] * du[c];
+          for (int c = 0; c < NXA; ++c) a += gh[NU + c] * dx[c];
+        } else if (q < 12) a += dx[q] + d / m * (sp.k1 * dx[q - 9] + dx[q - 6]);
+        else if (q == 12) a += dx[12] + d * (1 - gl) * du[6 * NV + 6];
+        else if (q < 16) a += dx[q] + d * (1 - gl) * du[6 * NV + q - 13];
+        else if (q == 16) a += dx[16] + d * (1 - gr) * du[6 * NV + 7];
+        else if (q < 20) a += dx[q] + d * (1 - gr) * du[6 * NV + 3 + q - 17];
+        else a += du[3 * (q - 20) + 2];
+        L(D::oXN1 + q) = a;
+      }
+      CMPC_SYNC();
+      if (lane < NXA) {
+        const double *stn = stage(k + 1);
+        double a = stn[D::gPV + lane];
+        for (int j = 0; j < NXA; ++j) a += stn[D::gPK + j * NXA + lane] * L(D::oXN1 + j);
+        glamn[(size_t)(k + 1) * NXA + lane] = a;
+        gdx[(size_t)(k + 1) * NXA + lane] = L(D::oXN1 + lane);
+      }
+      CMPC_SYNC();
+      if (lane < NXA) L(D::oXK + lane) = L(D::oXN1 + lane);
+      CMPC_SYNC();
+    }
+  }
+
+  // (Jg d)[r] for the stage whose x, dx, du, AL are staged in LDS (XK, XN1=dx, UK=du, AL)
+  CMPC_DEV double jg_dot(int k, int r, double lyap_dot) const {
+    const double muf = L(D::oHDR + 21);
+    const double *dx = &L(D::oXN1), *du = &L(D::oUK);
+    if (r == R_LYAP) return lyap_dot;
+    if (r == R_CZ) return dx[2];
+    if (r == R_HWC) return 2.0 * (L(D::oXK + 6) * dx[6] + L(D::oXK + 7) * dx[7] + L(D::oXK + 8) * dx[8]);
+    if (r < R_FRIC) {
+      const int q = r - R_BOX, f = q / 6, a = (q % 6) / 2, sgn = (q & 1) ? -1 : 1;
+      return sgn * gam_k(k, f) * dx[13 + 4 * f + a];
+    }
+    const int q = r - R_FRIC, v = q / 5, t = q % 5, f = v / NV;
+    const double gg = L(D::oSR + 17 + f);
+    const double fx = du[3 * v], fy = du[3 * v + 1], fz = du[3 * v + 2];
+    if (t == 0) return gg * (fx - muf * fz);
+    if (t == 1) return gg * (-fx - muf * fz);
+    if (t == 2) return gg * (fy - muf * fz);
+    if (t == 3) return gg * (-fy - muf * fz);
+    return -gg * fz;
+  }
+
+  // Slack / multiplier directions and the fraction-to-the-boundary step lengths.
+  CMPC_DEV void step_lengths(double mu, double &ap, double &ad) {
+    const double tau = fmax(0.99, 1 - mu);
+    double lap = 1.0, lad = 1.0;
+    for (int k = 0; k <= N; ++k) {
+      const double *st = stage(k);
+      for (int i = lane; i < NXA; i += 64) { L(D::oXK + i) = gx[(size_t)k * NXA + i]; L(D::oXN1 + i) = gdx[(size_t)k * NXA + i]; }
+      for (int i = lane; i < NU; i += 64) L(D::oUK + i) = (k < N) ? gdu[(size_t)k * NU + i] : 0.0;
+      if (lane < 19) L(D::oSR + lane) = (k < N) ? rec[24 + 19 * k + lane] : 0.0;
+      CMPC_SYNC();
+      double part = 0.0;
+      if (lane < NZ) part = st[D::gAL + lane] * ((lane < NU) ? L(D::oUK + lane) : L(D::oXN1 + lane - NU));
+      const double ldot = red_sum(part);
+      for (int r = lane; r < NI; r += 64) {
+        const double s = gsl[(size_t)k * NI + r], z = gz[(size_t)k * NI + r], g = st[D::gG + r];
+        double ds = 0.0, dz = 0.0;
+        if (z != 0.0) {                       // active rows carry z > 0
+          ds = -(g + s) - jg_dot(k, r, ldot);
+          dz = (mu - s * z - z * ds) / s;
+          if (ds < 0) lap = fmin(lap, -tau * s / ds);
+          if (dz < 0) lad = fmin(lad, -tau * z / dz);
+        }
+        gds[(size_t)k * NI + r] = ds; gdz[(size_t)k * NI + r] = dz;
+      }
+      CMPC_SYNC();
+    }
+    ap = red_min(lap); ad = red_min(lad);
+  }
+
+  CMPC_DEV void apply_step(double mu, double ap, double ad) {
+    for (int e = lane; e < (N + 1) * NXA; e += 64) {
+      if (e >= NXA) {
+        gx[e] += ap * gdx[e];
+        glam[e] += ap * (glamn[e] - glam[e]);
+      }
+    }
+    for (int e = lane; e < N * NU; e += 64) gu[e] += ap * gdu[e];
+    for (int e = lane; e < (N + 1) * NI; e += 64) {
+      double z = gz[e];
+      if (z != 0.0) {
+        const double s = gsl[e] + ap * gds[e];
+        z += ad * gdz[e];
+        const double lo = mu / s / 1e10, hi = mu / s * 1e10;
+        gsl[e] = s; gz[e] = fmin(fmax(z, lo), hi);
+      }
+    }
+    CMPC_SYNC();
+  }
+
+  // Initial point: warm start or hover forces; x_0 from the record; carried f_z states.
+  CMPC_DEV void initial_point(const double *warm) {
+    const double m = rec[20];
+    for (int e = lane; e < (N + 1) * NXA; e += 64) {
+      const int k = e / NXA, i = e % NXA;
+      double v = 0.0;
+      if (i < CMPC_NX) v = (warm && k >= 1) ? warm[(size_t)k * CMPC_NX + i] : rec[i];
+      gx[e] = v; glam[e] = 0.0;
+    }
+    for (int e = lane; e < N * NU; e += 64) {
+      const int k = e / NU, i = e % NU;
+      double v = 0.0, up = 0.0;
+      if (warm) { v = warm[(size_t)CMPC_NX * (N + 1) + e]; up = v; }
+      else if (i < 6 * NV && (i % 3) == 2) {
+        const double gl = rec[24 + 19 * k + 17], gr = rec[24 + 19 * k + 18];
+        v = m * sp.g / (NV * (gl + gr)) * (((i / 3) < NV) ? gl : gr);
+      }
+      gu[e] = v; gupx[e] = up;
+    }
+    CMPC_SYNC();
+    for (int e = lane; e < N * NF; e += 64) {
+      const int k = e / NF + 1, j = e % NF;
+      gx[(size_t)k * NXA + CMPC_NX + j] = gu[(size_t)(k - 1) * NU + 3 * j + 2];
+    }
+    CMPC_SYNC();
+  }
+
+  CMPC_DEV void init_slacks(double mu, double x0n2) {
+    for (int k = 0; k <= N; ++k) {
+      load_stage(k, false);
+      if (k < N) {
+        // only Fs is needed by the Lyapunov row
+        if (lane < 3) {
+          for (int f = 0; f < 2; ++f) {
+            double fs = 0;
+            for (int j = 0; j < NV; ++j) fs += L(D::oUK + 3 * (f * NV + j) + lane);
+            L(D::oMISC + 3 * f + lane) = fs;
+          }
+        }
+        CMPC_SYNC();
+      }
+      stage_ineq(k, x0n2);
+      for (int r = lane; r < NI; r += 64) {
+        const bool act = L(D::oW2 + r) != 0.0;
+        const double s = act ? fmax(-L(D::oGK + r), 1e-2) : 1.0;
+        gsl[(size_t)k * NI + r] = s;
+        gz[(size_t)k * NI + r] = act ? mu / s : 0.0;
+      }
+      CMPC_SYNC();
+    }
+  }
+
+  // ---------------------------------------------------------------------------------------
+  CMPC_DEV void solve(const double *warm, double *out, int32_t *status, int32_t *iters, double *kkt_out,
+                      bool dump = false) {
+    const double tol = sp.tol;
+    const double x0n2 = rec[6] * rec[6] + rec[7] * rec[7] + rec[8] * rec[8];
+    double mu = 0.1, reg_last = 0.0, kkt = INFINITY;
+    int st = CMPC_MAX_ITER, it = 0, n_acc = 0, n_stall = 0, polish = -1;
+    double dbg_ap = 0, dbg_ad = 0, dbg_nreg = 0, dbg_mu = 0;
+    dbg_on = dump;
+    initial_point(warm);
+    init_slacks(mu, x0n2);
+    CMPC_TICK_RESET();
+    for (it = 0; it <= sp.max_iter; ++it) {
+      double reg = 0.0;
+      Err er;
+      bool fail = false;
+      while (!matrix_sweep(mu, reg, x0n2, er)) {
+        CMPC_SYNC();
+        if (reg == 0.0) reg = (reg_last == 0.0) ? 1e-4 : fmax(1e-20, reg_last / 3);
+        else reg *= (reg_last == 0.0) ? 100.0 : 8.0;
+        dbg_nreg += 1;
+        if (reg > 1e20) { fail = true; break; }
+      }
+      if (fail) { st = CMPC_NUMERICAL; break; }
+      const double e_d = red_max(er.e_d), e_p = red_max(er.e_p), e_c = red_max(er.e_c), e_cmu = red_max(er.e_cmu);
+      const double sm = red_sum(er.sum_mult), nm = red_sum((double)er.n_mult);
+      const double sd = fmax(100.0, sm / fmax(nm, 1.0)) / 100.0;
+      kkt = fmax(fmax(e_d / sd, e_p), e_c / sd);
+      if (polish < 0) {
+        if (kkt <= tol) { polish = POLISH_ITERS; mu = tol / 10; }
+        else {
+          n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
+          if (n_acc >= ACC_ITERS) { st = CMPC_CONVERGED; break; }
+        }
+      }
+      if (polish == 0) { st = CMPC_CONVERGED; break; }
+      if (it == sp.max_iter) { if (polish >= 0) st = CMPC_CONVERGED; break; }
+      if (!(kkt < INFINITY) || n_stall >= STALL_ITERS) { st = CMPC_NUMERICAL; break; }
+      if (reg > 0) reg_last = reg;
+      if (polish > 0) --polish;
+      else
+        while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
+          mu = fmax(tol / 10, fmin(0.2 * mu, mu * sqrt(mu)));
+      vector_sweeps(mu);
+      CMPC_TICK(6);
+      double ap, ad;
+      step_lengths(mu, ap, ad);
+      n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
+      dbg_ap = ap; dbg_ad = ad; dbg_mu = mu;
+      if (sp.reserved > 0 && it == sp.reserved - 1) break;   // diagnostic: stop before applying step
+      apply_step(mu, ap, ad);
+      CMPC_TICK(7);
+    }
+    // write X (20 x (N+1)) then U (nu x N)
+    for (int e = lane; e < (N + 1) * CMPC_NX; e += 64) out[e] = gx[(size_t)(e / CMPC_NX) * NXA + (e % CMPC_NX)];
+    for (int e = lane; e < N * NU; e += 64) out[(size_t)CMPC_NX * (N + 1) + e] = gu[e];
+    if (lane == 0) { *status = st; *iters = it; *kkt_out = kkt; }
+    if (dump && ka.dbg) {
+      double *d = ka.dbg;
+      for (int e = lane; e < (N + 1) * NXA; e += 64) { d[e] = gx[e]; d[(N + 1) * NXA + e] = glam[e]; }
+      d += 2 * (N + 1) * NXA;
+      for (int e = lane; e < (N + 1) * NI; e += 64) { d[e] = gsl[e]; d[(N + 1) * NI + e] = gz[e]; }
+      d += 2 * (N + 1) * NI;
+      if (lane == 0) { d[0] = mu; d[1] = reg_last; d[2] = dbg_ap; d[3] = dbg_ad; d[4] = dbg_nreg; }
+      for (int kk = 15; kk <= 18; ++kk)
+        for (int e = lane; e < NXA * NXA; e += 64) ka.dbg[50000 + (kk - 15) * 1000 + e] = stage(kk)[D::gPK + e];
+      d += 8;
+      // per-stage vectors of the last Newton step: h (NZ), b (NXA), l (NU), p (NXA), du (NU), dx (NXA)
+      for (int k = 0; k <= N; ++k) {
+        const double *sk = stage(k);
+        double *o = d + (size_t)k * (NZ + 3 * NXA + 3 * NU);
+        for (int e = lane; e < NU; e += 64) o[NZ + 3 * NXA + 2 * NU + e] = sk[D::gLAM + e * NU + e];
+        for (int e = lane; e < NZ; e += 64) o[e] = sk[D::gH0 + e] + dbg_mu * sk[D::gH1 + e];
+        for (int e = lane; e < NXA; e += 64) { o[NZ + e] = sk[D::gB + e]; o[NZ + NXA + NU + e] = sk[D::gPV + e]; o[NZ + 2 * NXA + 2 * NU + e] = gdx[(size_t)k * NXA + e]; }
+        for (int e = lane; e < NU; e += 64) { o[NZ + NXA + e] = sk[D::gL + e]; o[NZ + 2 * NXA + NU + e] = gdu[(size_t)k * NU + e]; }
+      }
+    }
+#if defined(CMPC_PROFILE) && !defined(CMPC_HOST_EMU)
+    if (lane == 0 && ka.prof)
+      for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);
+#endif
+    CMPC_SYNC();
+  }
+};
+
+#endif  // CMPC_NO_DEVICE_CODE
+}  // namespace cmpc

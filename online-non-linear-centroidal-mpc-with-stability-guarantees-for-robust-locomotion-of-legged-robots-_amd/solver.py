@@ -1,0 +1,85 @@
+"""Batched solver front end: torch tensors in, torch tensors out, HIP kernels in between.
+
+``BatchedCentroidalMPC`` owns one C-ABI handle (one GPU).  PyTorch is only the allocator
+and stream provider; all arithmetic happens in libcmpc_amd.so.  It replaces the
+reference's ``self.opt.solve()`` (code/centroidal_mpc_vertices.py:606) for B instances at once.
+"""
+import ctypes
+
+import torch
+
+from . import capi
+from .problem import ProblemSpec, to_cspec
+
+STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_NUMERICAL = 0, 1, 2
+
+
+class BatchedCentroidalMPC:
+    def __init__(self, spec: ProblemSpec, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedCentroidalMPC needs a ROCm GPU: there is no CPU fallback")
+        self.spec = spec
+        self.device = (torch.device("cuda", torch.cuda.current_device()) if device is None
+                       else torch.device(device))
+        self._lib = capi.load()
+        self._cspec = to_cspec(spec)
+        h = ctypes.c_void_p()
+        rc = self._lib.cmpc_create(ctypes.byref(self._cspec), self.device.index or 0, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError("cmpc_create failed: " + self._lib.cmpc_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cmpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def workspace_bytes(self, B):
+        return self._lib.cmpc_workspace_bytes(ctypes.byref(self._cspec), B)
+
+    def solve(self, records, warm=None, out=None):
+        """records (B, nrec) fp64 on this GPU -> (XU (B, nsol), status, iters, kkt), all on the GPU.
+
+        Asynchronous on torch's current stream.  ``warm`` (B, nsol) is the previous solution
+        (initial guess and proximal centre), the batched form of ``opt.set_initial``
+        (code/centroidal_mpc_vertices.py:630-631).
+        """
+        sp = self.spec
+        if not (records.is_cuda and records.dtype == torch.float64 and records.is_contiguous()):
+            raise ValueError("records must be a contiguous fp64 CUDA tensor")
+        if records.dim() != 2 or records.shape[1] != sp.nrec:
+            raise ValueError(f"records must have shape (B, {sp.nrec})")
+        B = records.shape[0]
+        if warm is not None:
+            if not (warm.is_cuda and warm.dtype == torch.float64 and warm.is_contiguous()
+                    and tuple(warm.shape) == (B, sp.nsol)):
+                raise ValueError(f"warm must be a contiguous fp64 CUDA tensor of shape (B, {sp.nsol})")
+        if out is None:
+            out = torch.empty((B, sp.nsol), dtype=torch.float64, device=records.device)
+        status = torch.empty(B, dtype=torch.int32, device=records.device)
+        iters = torch.empty(B, dtype=torch.int32, device=records.device)
+        kkt = torch.empty(B, dtype=torch.float64, device=records.device)
+        if B == 0:
+            return out, status, iters, kkt
+        stream = torch.cuda.current_stream(records.device).cuda_stream
+        rc = self._lib.cmpc_solve_batch(self._h, B, records.data_ptr(),
+                                        warm.data_ptr() if warm is not None else None,
+                                        out.data_ptr(), status.data_ptr(), iters.data_ptr(), kkt.data_ptr(),
+                                        ctypes.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("cmpc_solve_batch failed: " + self._lib.cmpc_last_error(self._h).decode())
+        return out, status, iters, kkt
+
+    def last_kernel_ms(self):
+        """Duration of the last solve's kernel (HIP events on the launch stream); synchronises."""
+        ms = ctypes.c_float()
+        rc = self._lib.cmpc_last_kernel_ms(self._h, ctypes.byref(ms))
+        if rc != 0:
+            raise RuntimeError(self._lib.cmpc_last_error(self._h).decode())
+        return ms.value

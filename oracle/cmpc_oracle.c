@@ -34,6 +34,16 @@
 #define MAXNZ (MAXNU + MAXNX)
 #define MAXNI (15 + 10 * MAXNV)
 
+/* termination safeguards (mirrored by the HIP solver) */
+#define ACC_FACTOR 100.0
+#define ACC_ITERS 8
+#define STALL_STEP 1e-7
+#define STALL_ITERS 6
+/* after the tolerance is first met: POLISH_ITERS more Newton iterations at the final barrier value,
+ * so that the returned point is the mu = tol/10 central-path point to ~1e-12 whatever path led there
+ * (directions whose only curvature is the proximal term need this to be reproducible). */
+#define POLISH_ITERS 2
+
 /* inequality row slots of one stage */
 enum { R_LYAP = 0, R_CZ = 1, R_HWC = 2, R_BOX = 3, R_FRIC = 15 };
 
@@ -111,6 +121,9 @@ static void stage_dynamics(const prob_t *P, int k, const double *x, const double
 #define HD(a, bb) Hd[(a) * nz + (bb)]
   if (G) for (int i = 0; i < CMPC_NX; ++i) GA(i, i) = 1.0;
   double pi[3] = {0, 0, 0};
+#ifdef CMPC_NO_DYN_CURV
+  Hd = NULL;
+#endif
   if (Hd) for (int a = 0; a < 3; ++a) pi[a] = d * lamn[6 + a];
   for (int f = 0; f < 2; ++f) {
     const double yaw = x[iy[f]], *pf = x + ip[f];
@@ -569,7 +582,7 @@ static void initial_point(const prob_t *P, work_t *W, const double *warm) {
 
 /* One interior-point solve.  out: X then U (reference layout). */
 static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm, double *out,
-                      stats_t *st, int verbose) {
+                      stats_t *st, int verbose, double *full) {
   prob_t Pb; prob_init(&Pb, sp, rec);
   const prob_t *P = &Pb;
   const int N = P->N, nx = P->nx, nu = P->nu, nz = P->nz, ni = P->ni;
@@ -589,7 +602,8 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     }
   }
   st->status = CMPC_MAX_ITER; st->n_reg = 0;
-  int it;
+  int it, n_acc = 0, n_stall = 0, polish = -1;
+  double dbg_ap = 0, dbg_ad = 0;
   double kkt = INFINITY;
   double *xn = (double *)malloc(sizeof(double) * nx);
   for (it = 0; it <= sp->max_iter; ++it) {
@@ -598,7 +612,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     int n_mult = 0;
     for (int k = 0; k <= N; ++k) {
       double *x = W->x + (size_t)k * nx, *u = W->u + (size_t)k * nu;
-      double *H = W->H + (size_t)k * nz * nz, *h = W->h + (size_t)k * nz, *ho = W->hobj + (size_t)k * nz;
+      double *H = W->H + (size_t)k * nz * nz, *ho = W->hobj + (size_t)k * nz;
       double *g = W->g + (size_t)k * ni, *Jg = W->Jg + (size_t)k * ni * nz;
       double *s = W->s + (size_t)k * ni, *z = W->z + (size_t)k * ni;
       int *act = W->act + (size_t)k * ni;
@@ -632,11 +646,21 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     kkt = fmax(fmax(e_d / sd, e_p), e_c / sd);
     if (verbose)
       printf("it %3d f=%.8e d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e\n", it, fobj, e_d / sd, e_p, e_c / sd, mu, reg_last);
-    if (kkt <= tol) { st->status = CMPC_CONVERGED; break; }
-    if (it == sp->max_iter) break;
-    if (!isfinite(kkt)) { st->status = CMPC_NUMERICAL; break; }
-    while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
-      mu = fmax(tol / 10, fmin(0.2 * mu, pow(mu, 1.5)));
+    if (polish < 0) {
+      if (kkt <= tol) { polish = POLISH_ITERS; mu = tol / 10; }
+      else {
+        /* IPOPT-style acceptable level: ACC_ITERS consecutive iterates within ACC_FACTOR*tol */
+        n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
+        if (n_acc >= ACC_ITERS) { st->status = CMPC_CONVERGED; break; }
+      }
+    }
+    if (polish == 0) { st->status = CMPC_CONVERGED; break; }
+    if (it == sp->max_iter) { if (polish >= 0) st->status = CMPC_CONVERGED; break; }
+    if (!isfinite(kkt) || n_stall >= STALL_ITERS) { st->status = CMPC_NUMERICAL; break; }
+    if (polish > 0) --polish;
+    else
+      while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
+        mu = fmax(tol / 10, fmin(0.2 * mu, mu * sqrt(mu)));
     /* ---- barrier-augmented QP data ---- */
     for (int k = 0; k <= N; ++k) {
       double *H = W->H + (size_t)k * nz * nz, *h = W->h + (size_t)k * nz, *ho = W->hobj + (size_t)k * nz;
@@ -685,6 +709,9 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
         W->ds[(size_t)k * ni + i] = ds; W->dz[(size_t)k * ni + i] = dz;
       }
     }
+    n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;   /* no room to move: locally infeasible */
+    dbg_ap = ap; dbg_ad = ad;
+    if (sp->reserved > 0 && it == sp->reserved - 1) break;   /* diagnostic: stop before applying the step */
     for (int k = 0; k <= N; ++k) {
       if (k >= 1) for (int i = 0; i < nx; ++i) {
         W->x[(size_t)k * nx + i] += ap * W->dx[(size_t)k * nx + i];
@@ -704,6 +731,25 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
   for (int k = 0; k <= N; ++k) memcpy(out + (size_t)k * CMPC_NX, W->x + (size_t)k * nx, sizeof(double) * CMPC_NX);
   for (int k = 0; k < N; ++k)
     memcpy(out + (size_t)CMPC_NX * (N + 1) + (size_t)k * nu, W->u + (size_t)k * nu, sizeof(double) * nu);
+  if (full) {   /* x, lam ((N+1) x nx each), s, z ((N+1) x ni each) */
+    memcpy(full, W->x, sizeof(double) * (N + 1) * nx); full += (N + 1) * nx;
+    memcpy(full, W->lam, sizeof(double) * (N + 1) * nx); full += (N + 1) * nx;
+    memcpy(full, W->s, sizeof(double) * (N + 1) * ni); full += (N + 1) * ni;
+    memcpy(full, W->z, sizeof(double) * (N + 1) * ni); full += (N + 1) * ni;
+    full[0] = mu; full[1] = reg_last; full[2] = dbg_ap; full[3] = dbg_ad; full[4] = st->n_reg;
+    if (N >= 18) for (int kk = 15; kk <= 18; ++kk) memcpy(full + 20000 + (kk - 15) * 1000, W->P + (size_t)kk * nx * nx, sizeof(double) * nx * nx);
+    full += 8;
+    for (int k = 0; k <= N; ++k) {   /* vectors of the last Newton step */
+      double *o = full + (size_t)k * (nz + 3 * nx + 3 * nu);
+      for (int e = 0; e < nu; ++e) o[nz + 3 * nx + 2 * nu + e] = W->Lam[(size_t)k * nu * nu + e * nu + e];
+      memcpy(o, W->h + (size_t)k * nz, sizeof(double) * nz);
+      memcpy(o + nz, W->b + (size_t)k * nx, sizeof(double) * nx);
+      memcpy(o + nz + nx, W->l + (size_t)k * nu, sizeof(double) * nu);
+      memcpy(o + nz + nx + nu, W->p + (size_t)k * nx, sizeof(double) * nx);
+      memcpy(o + nz + 2 * nx + nu, W->du + (size_t)k * nu, sizeof(double) * nu);
+      memcpy(o + nz + 2 * nx + 2 * nu, W->dx + (size_t)k * nx, sizeof(double) * nx);
+    }
+  }
   st->iters = it; st->kkt = kkt; st->mu = mu; st->reg_last = reg_last;
   work_free(W);
 }
@@ -722,7 +768,7 @@ int cmpc_oracle_solve(const cmpc_spec *sp, const double *rec, const double *warm
                       int32_t *status, int32_t *iters, double *kkt, int verbose) {
   if (sp->N < 1 || sp->N > CMPC_MAX_N || (sp->nv != 4 && sp->nv != 8)) return 1;
   stats_t st;
-  solve_one(sp, rec, warm, out, &st, verbose);
+  solve_one(sp, rec, warm, out, &st, verbose, NULL);
   if (status) *status = st.status;
   if (iters) *iters = st.iters;
   if (kkt) *kkt = st.kkt;
@@ -739,12 +785,19 @@ int cmpc_oracle_solve_batch(const cmpc_spec *sp, int32_t B, const double *recs, 
 #endif
   for (int b = 0; b < B; ++b) {
     stats_t st;
-    solve_one(sp, recs + b * nrec, warm ? warm + b * nsol : NULL, out + b * nsol, &st, 0);
+    solve_one(sp, recs + b * nrec, warm ? warm + b * nsol : NULL, out + b * nsol, &st, 0, NULL);
     if (status) status[b] = st.status;
     if (iters) iters[b] = st.iters;
     if (kkt) kkt[b] = st.kkt;
   }
   return 0;
+}
+
+/* Diagnostic: solve and also return the full primal-dual iterate (x, lam, s, z). */
+int cmpc_oracle_solve_full(const cmpc_spec *sp, const double *rec, const double *warm, double *out, double *full) {
+  stats_t st;
+  solve_one(sp, rec, warm, out, &st, 0, full);
+  return st.status;
 }
 
 /* Function values on a full primal point w = [X (20 x (N+1)), U (nu x N)] in reference layout:
@@ -755,7 +808,7 @@ int cmpc_oracle_eval(const cmpc_spec *sp, const double *rec, const double *w, co
                      double *cost, double *defect, double *ineq, int32_t *act_out) {
   prob_t Pb; prob_init(&Pb, sp, rec);
   const prob_t *P = &Pb;
-  const int N = P->N, nx = P->nx, nu = P->nu, ni = P->ni, nv = P->nv;
+  const int N = P->N, nu = P->nu, ni = P->ni, nv = P->nv;
   double x[MAXNX], xp[MAXNX], xn[MAXNX], u[MAXNU], g[MAXNI];
   int act[MAXNI];
   double J = 0;
