@@ -1,0 +1,84 @@
+"""The C-ABI library loads and exports every symbol include/cmpc.h declares; host-only entry points
+behave (no GPU needed, no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import build as _b
+from cmpc_amd import capi
+from cmpc_amd.problem import CSpec, ProblemSpec, to_cspec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _b.build_hip()
+    return capi.load()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "cmpc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cmpc_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_all_exported(lib):
+    names = _declared_functions()
+    assert set(names) == set(capi.SYMBOLS), (names, capi.SYMBOLS)
+    raw = ctypes.CDLL(capi.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/cmpc.h but not exported"
+
+
+def test_default_spec_and_struct_layout(lib):
+    c = CSpec()
+    lib.cmpc_default_spec(ctypes.byref(c), 20, 4)
+    py = to_cspec(ProblemSpec(N=20, nv=4))
+    for name, _ in CSpec._fields_:
+        if name in ("reserved", "max_iter", "tol"):
+            continue
+        a, b = getattr(c, name), getattr(py, name)
+        if name == "box":
+            assert list(a) == list(b)
+        else:
+            assert a == b, name
+    assert ctypes.sizeof(CSpec) == 4 * 4 + 19 * 8            # 4 int32 + 19 doubles, no padding surprises
+    assert lib.cmpc_version().decode().startswith("cmpc_amd")
+
+
+def test_workspace_bytes_and_argument_checks(lib):
+    c = to_cspec(ProblemSpec(N=20, nv=4))
+    small, big = lib.cmpc_workspace_bytes(ctypes.byref(c), 16), lib.cmpc_workspace_bytes(ctypes.byref(c), 1 << 20)
+    assert 0 < small < big                                  # bounded by the resident grid, not by B
+    assert lib.cmpc_workspace_bytes(ctypes.byref(c), 1 << 21) == big
+    bad = to_cspec(ProblemSpec(N=20, nv=4)); bad.nv = 5
+    assert lib.cmpc_workspace_bytes(ctypes.byref(bad), 16) == 0
+    h = ctypes.c_void_p()
+    assert lib.cmpc_create(ctypes.byref(bad), 0, ctypes.byref(h)) != 0
+    assert b"invalid spec" in lib.cmpc_last_error(None)
+    assert lib.cmpc_solve_batch(None, 1, None, None, None, None, None, None, None) != 0
+    assert lib.cmpc_destroy(None) == 0
+
+
+def test_no_cpu_fallback_in_product_path():
+    """The package must not import anything from oracle/ or tests/emu (parity would be void)."""
+    pkg = os.path.dirname(capi.__file__)
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            for line in src.splitlines():
+                if line.lstrip().startswith(("import ", "from ")):
+                    assert "oracle" not in line and "emu" not in line and "tests" not in line, (fn, line)
+            assert "libcmpc_oracle" not in src and "libcmpc_emu" not in src, fn
+
+
+def test_solver_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cmpc_amd.solver import BatchedCentroidalMPC
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        BatchedCentroidalMPC(ProblemSpec())

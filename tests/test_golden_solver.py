@@ -1,0 +1,26 @@
+"""Committed known-answer vectors (tests/golden/solver_kat_*.npz): the oracle must keep reproducing
+them on CPU; the HIP solver reproduces them in tests/test_gpu_parity.py."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_inf
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FILES = sorted(glob.glob(os.path.join(GOLD, "solver_kat_*.npz")))
+
+
+def test_kat_files_present():
+    assert len(FILES) >= 4
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_oracle_reproduces_golden_vectors(oracle, path):
+    kat = np.load(path)
+    cs = oracle.default_spec(N=int(kat["N"]), nv=int(kat["nv"]), tol=1e-10, max_iter=300,
+                             k1=float(kat["k1"]), k2=float(kat["k2"]))
+    sol, st, _, _ = oracle.solve_batch(cs, kat["records"])
+    assert (st == 0).all()
+    assert rel_inf(sol, kat["solutions"]).max() < 1e-8

@@ -1,0 +1,95 @@
+"""Host logic against the reference's own fixtures (code/Debug/*, see tests/golden/README.md)."""
+import os
+
+import numpy as np
+
+from cmpc_amd import workloads as wl
+from cmpc_amd.problem import ProblemSpec, build_record, contact_flags
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_plan_positions_match_reference_dump(scene):
+    lines = [l.strip() for l in open(os.path.join(GOLD, "MPC_pose_contact_ref.txt"))]
+    gold = np.array([float(x) for x in lines if x and x != "end"]).reshape(20, 3)
+    assert np.array_equal(scene.planner.plan_positions(), gold)          # bit-exact
+
+
+def test_swing_trajectories_match_reference_dump(scene):
+    pre = scene.ftg.generate_feet_trajectories_pre()
+    for foot, name in (("lfoot", "pos_lfoot_pre_trj.txt"), ("rfoot", "pos_rfoot_pre_trj.txt")):
+        gold = np.loadtxt(os.path.join(GOLD, name))
+        mine = np.array([pre[foot][t][0]['pos'][3:6] for t in range(gold.shape[0])])
+        assert np.array_equal(mine, gold)                                  # bit-exact
+
+
+def test_plan_structure(scene):
+    pl = scene.planner
+    assert len(pl.plan) == 20
+    assert pl.plan[0]['ss_duration'] == 0 and pl.plan[0]['ds_duration'] == 200
+    assert [s['foot_id'] for s in pl.plan[:4]] == ['rfoot', 'lfoot', 'rfoot', 'lfoot']
+    assert pl.get_step_index_at_time(0) == 0 and pl.get_step_index_at_time(199) == 0
+    assert pl.get_step_index_at_time(200) == 1 and pl.get_phase_at_time(200) == 'ss'
+    assert pl.get_phase_at_time(269) == 'ss' and pl.get_phase_at_time(270) == 'ds'
+    assert pl.get_step_index_at_time(10 ** 6) is None
+    assert pl.position_contacts_ref['contact_left'].shape == (2000, 6)
+
+
+def test_contact_flags_and_tables(scene):
+    pl = scene.planner
+    for t in (0, 150, 199, 200, 269, 270, 305, 1234, 1700):
+        gl, gr = contact_flags(pl, t, 20)
+        assert np.array_equal(gl, scene.gl_tab[t:t + 21]) and np.array_equal(gr, scene.gr_tab[t:t + 21])
+        assert set(np.unique(np.concatenate([gl, gr]))) <= {0.0, 1.0}
+        assert np.all(gl + gr >= 1)                                         # never both feet in the air
+
+
+def test_vectorised_builder_equals_scalar_front_half(scene):
+    spec = ProblemSpec(N=20)
+    rng = np.random.default_rng(5)
+    ts = rng.integers(0, scene.t_max(20), size=40)
+    B = len(ts)
+    com, dcom, hw, th = rng.normal(size=(B, 3)), rng.normal(size=(B, 3)), rng.normal(size=(B, 3)), rng.normal(size=(B, 3))
+    yl, yr = rng.normal(size=B), rng.normal(size=B)
+    mass, mu = rng.uniform(30, 50, B), rng.uniform(0.3, 0.9, B)
+    batch = scene.build_records(spec, ts, com, dcom, hw, th, yl, yr, mass, mu)
+    for b, t in enumerate(ts):
+        one = build_record(spec, scene.planner, scene.com_ref, int(t), com[b], dcom[b], hw[b], th[b], yl[b], yr[b],
+                           mass[b], mu[b])
+        assert np.array_equal(one, batch[b])
+
+
+def test_record_layout(scene):
+    spec = ProblemSpec(N=10)
+    t = 640
+    rec = build_record(spec, scene.planner, scene.com_ref, t, [1, 2, 3], [4, 5, 6], [7, 8, 9], [.1, .2, .3], 0.4, 0.5, 41.0, 0.6)
+    assert rec.shape == (24 + 19 * 10,)
+    assert list(rec[0:12]) == [1, 2, 3, 4, 5, 6, 7, 8, 9, .1, .2, .3] and rec[12] == 0.4 and rec[16] == 0.5
+    assert rec[20] == 41.0 and rec[21] == 0.6
+    st = rec[24:].reshape(10, 19)
+    for i in range(10):
+        tt = t + 1 + i
+        assert st[i, 0] == scene.com_ref['pos_x'][tt] and st[i, 4] == scene.com_ref['vel_y'][tt]
+        assert st[i, 8] == scene.com_ref['acc_z'][tt]
+        assert np.array_equal(st[i, 9:12], scene.pose_l[tt, 3:6]) and st[i, 16] == scene.pose_r[tt, 2]
+    # foot positions in x0 come from the plan, not from the measured feet (reference :493-509)
+    idx = scene.planner.get_step_index_at_time(t - 70)
+    assert np.array_equal(rec[13:16], scene.planner.plan[idx + (idx - 1) % 2]['pos'])
+    assert np.array_equal(rec[17:20], scene.planner.plan[idx + (idx % 2)]['pos'])
+
+
+def test_com_reference_shape_and_continuity(scene):
+    ref = scene.com_ref
+    assert len(ref['pos_x']) == 1971 and len(ref['pos_y']) == 2000
+    assert np.all(np.asarray(ref['pos_z']) == 0.72)
+    px = np.asarray(ref['pos_x'])
+    assert np.abs(np.diff(px)).max() < 3e-3                                  # C0 and smooth
+    assert abs(px[-1] - 2.07) < 2e-2
+
+
+def test_workload_generators_are_deterministic():
+    for name in wl.CONFIGS:
+        s1, r1 = wl.make_workload(name, B=16)
+        s2, r2 = wl.make_workload(name, B=16)
+        assert np.array_equal(r1, r2) and r1.shape == (16, s1.nrec)
+        assert np.isfinite(r1).all()
