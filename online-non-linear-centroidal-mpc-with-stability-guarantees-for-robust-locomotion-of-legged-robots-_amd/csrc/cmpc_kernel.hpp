@@ -1082,6 +1082,7 @@ template <int NV> struct Solver {
     const double x0n2 = rec[6] * rec[6] + rec[7] * rec[7] + rec[8] * rec[8];
     double mu = 0.1, reg_last = 0.0, kkt = INFINITY;
     int st = CMPC_MAX_ITER, it = 0, n_acc = 0, n_stall = 0, polish = -1;
+    bool polish_spent = false;
     double dbg_ap = 0, dbg_ad = 0, dbg_nreg = 0, dbg_mu = 0;
     dbg_on = dump;
     initial_point(warm);
@@ -1103,9 +1104,12 @@ template <int NV> struct Solver {
       const double sm = red_sum(er.sum_mult), nm = red_sum((double)er.n_mult);
       const double sd = fmax(100.0, sm / fmax(nm, 1.0)) / 100.0;
       kkt = fmax(fmax(e_d / sd, e_p), e_c / sd);
+      if (polish >= 0 && kkt > ACC_FACTOR * tol) { polish = -1; polish_spent = true; }   // polishing lost ground
       if (polish < 0) {
-        if (kkt <= tol) { polish = POLISH_ITERS; mu = tol / 10; }
-        else {
+        if (kkt <= tol) {
+          if (polish_spent) { st = CMPC_CONVERGED; break; }
+          polish = POLISH_ITERS; mu = tol / 10;
+        } else {
           n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
           if (n_acc >= ACC_ITERS) { st = CMPC_CONVERGED; break; }
         }

@@ -47,7 +47,7 @@ class ProblemSpec:
     prox: float = 1e-4            # build-defined proximal weight on U
     relax: float = 1e-8           # IPOPT bound_relax_factor
     tol: float = 1e-8             # KKT tolerance of the batched solver
-    max_iter: int = 60
+    max_iter: int = 100
 
     @property
     def nu(self):

@@ -602,7 +602,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     }
   }
   st->status = CMPC_MAX_ITER; st->n_reg = 0;
-  int it, n_acc = 0, n_stall = 0, polish = -1;
+  int it, n_acc = 0, n_stall = 0, polish = -1, polish_spent = 0;
   double dbg_ap = 0, dbg_ad = 0;
   double kkt = INFINITY;
   double *xn = (double *)malloc(sizeof(double) * nx);
@@ -646,9 +646,12 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     kkt = fmax(fmax(e_d / sd, e_p), e_c / sd);
     if (verbose)
       printf("it %3d f=%.8e d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e\n", it, fobj, e_d / sd, e_p, e_c / sd, mu, reg_last);
+    if (polish >= 0 && kkt > ACC_FACTOR * tol) { polish = -1; polish_spent = 1; }   /* polishing lost ground */
     if (polish < 0) {
-      if (kkt <= tol) { polish = POLISH_ITERS; mu = tol / 10; }
-      else {
+      if (kkt <= tol) {
+        if (polish_spent) { st->status = CMPC_CONVERGED; break; }
+        polish = POLISH_ITERS; mu = tol / 10;
+      } else {
         /* IPOPT-style acceptable level: ACC_ITERS consecutive iterates within ACC_FACTOR*tol */
         n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
         if (n_acc >= ACC_ITERS) { st->status = CMPC_CONVERGED; break; }

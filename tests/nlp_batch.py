@@ -51,7 +51,12 @@ def residuals(spec, rec, sol):
         cone = np.maximum(np.abs(fx), np.abs(fy)) - mu[:, None] * fz
         out["cone"] = np.maximum(out["cone"], (gam * cone).max(axis=1))
         out["unilateral"] = np.maximum(out["unilateral"], (gam * -fz).max(axis=1))
-        out["swing_force"] = np.maximum(out["swing_force"], ((1 - gam)[:, :, None] * np.abs(F)).max(axis=(1, 2)))
+        # a foot in the air carries nothing -- except on its first airborne stage, where the rate term
+        # gamma[k-1]*(fz[k]-fz[k-1])^2 (reference :343-351) still ties fz to the stance value
+        if k >= 1:
+            gprev = np.stack([gl[:, k - 1]] * 4 + [gr[:, k - 1]] * 4, axis=1)
+            air = (1 - gam) * (1 - gprev)
+            out["swing_force"] = np.maximum(out["swing_force"], (air[:, :, None] * np.abs(F)).max(axis=(1, 2)))
         if k >= 1:
             out["height"] = np.maximum(out["height"], x[:, 2] - spec.cz_max)
         # Lyapunov row (:202-220), written on the next state as in the reference
