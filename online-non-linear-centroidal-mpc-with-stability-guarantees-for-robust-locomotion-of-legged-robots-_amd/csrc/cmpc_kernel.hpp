@@ -26,11 +26,23 @@
 #define CMPC_DEV __device__ __forceinline__
 #define CMPC_DEVN __device__ __noinline__
 #define CMPC_LANE ((int)threadIdx.x)
-#ifdef CMPC_EXPERIMENT_INV
-#define CMPC_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
-#else
-#define CMPC_SYNC() __syncthreads()
-#endif
+// One wavefront per workgroup: LDS operations of a wave execute in issue order, so an LDS hand-off
+// between lanes needs no s_barrier -- only that the compiler neither caches nor reorders LDS
+// accesses across it.  CMPC_SYNC() is that (plus lgkmcnt(0)); it deliberately does NOT wait for
+// outstanding global stores (a __syncthreads() would add vmcnt(0): ~2 us after every spill).
+// CMPC_SYNC_GLOBAL() is the full fence, used where lanes exchange data through the global slab.
+#define CMPC_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define CMPC_SYNC_GLOBAL() __syncthreads()
+// value held by lane `src` (wave-uniform index) broadcast to every lane, no LDS round trip
+static __device__ __forceinline__ double cmpc_bcast(double v, int src) {
+  union { double d; int i[2]; } u; u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+  return u.d;
+}
+#define CMPC_BCAST(v, src) cmpc_bcast((v), (src))
+// keeps the scheduler from hoisting every LDS read of an unrolled phase to its top (live ranges)
+#define CMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 // Optional phase timers (diagnostic build only, -DCMPC_PROFILE): cycles per phase summed over the
@@ -155,7 +167,7 @@ template <int NV> struct Solver {
   // per-lane column list of [B A]: rows / coefficients (id, h0, h1, h2, sp1, sp2)
   int lr[6];
   double lg[6];
-  long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  long long tprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
   bool dbg_on = false;
 
   CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
@@ -625,90 +637,134 @@ template <int NV> struct Solver {
 
   // M += [B A]' P [B A]  (lower triangle, row owner), using T = P [B A] staged by column halves.
   CMPC_DEV void add_GtPG() {
+    // Register-blocked so that every LDS read of a phase is independent of the others (one wave per
+    // SIMD has nothing else to hide the ~100-cycle LDS latency behind).
     for (int half = 0; half < 2; ++half) {
       const int c0 = half * D::TH, c1 = (c0 + D::TH < NZ) ? c0 + D::TH : NZ;
-      if (lane >= c0 && lane < c1) {
-#pragma unroll 4
-        for (int q = 0; q < NXA; ++q) {
-          double a = 0.0;
+      if (lane >= c0 && lane < c1) {           // column `lane` of T = P [B A]
+        double acc[NXA];
 #pragma unroll
-          for (int n = 0; n < 6; ++n) a += lg[n] * L(D::oP + q * D::PS + lr[n]);
-          L(D::oT + q * D::TS + (lane - c0)) = a;
+        for (int q = 0; q < NXA; ++q) acc[q] = 0.0;
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+          const double g = lg[n];
+          const double *pc = &L(D::oP + lr[n]);
+#pragma unroll
+          for (int q = 0; q < NXA; ++q) acc[q] += g * pc[q * D::PS];
+          CMPC_SCHED_FENCE();
         }
+#pragma unroll
+        for (int q = 0; q < NXA; ++q) L(D::oT + q * D::TS + (lane - c0)) = acc[q];
       }
       CMPC_SYNC();
-      if (lane < NZ) {
+      CMPC_TICK(10);
+      if (lane >= c0 && lane < NZ) {           // row `lane` of M, columns c0 .. min(lane, c1-1)
         const int iend = (lane < c1 - 1) ? lane : c1 - 1;
-        double *row = &L(D::oM + tri(lane));
-#pragma unroll 4
-        for (int i = c0; i <= iend; ++i) {
-          double a = 0.0;
+        double acc[D::TH];
 #pragma unroll
-          for (int n = 0; n < 6; ++n) a += lg[n] * L(D::oT + lr[n] * D::TS + (i - c0));
-          row[i] += a;
+        for (int i = 0; i < D::TH; ++i) acc[i] = 0.0;
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+          const double g = lg[n];
+          const double *tr = &L(D::oT + lr[n] * D::TS);
+#pragma unroll
+          for (int i = 0; i < D::TH; ++i) acc[i] += g * tr[i];
+          CMPC_SCHED_FENCE();
         }
+        double *row = &L(D::oM + tri(lane) + c0);
+#pragma unroll
+        for (int i = 0; i < D::TH; ++i)
+          if (c0 + i <= iend) row[i] += acc[i];
       }
       CMPC_SYNC();
     }
   }
 
   // Cholesky of the input block, Ls, Schur complement.  Returns false on a non-positive pivot.
+  // Left-looking in panels of 4 columns: the four dot products share the loads of the lane's own row
+  // and are independent; the 4x4 panel itself is factorised in registers with readlane broadcasts.
   CMPC_DEV bool factor_stage(int k) {
     double *M = &L(D::oM);
-    for (int j = 0; j < NU; ++j) {
-      double acc = 0.0;
-      if (lane >= j && lane < NZ) {
-        const double *ri = M + tri(lane), *rj = M + tri(j);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int q = 0;
-        for (; q + 4 <= j; q += 4) {             // independent partial sums: LDS reads batch up
-          a0 += ri[q] * rj[q]; a1 += ri[q + 1] * rj[q + 1];
-          a2 += ri[q + 2] * rj[q + 2]; a3 += ri[q + 3] * rj[q + 3];
-        }
-        for (; q < j; ++q) a0 += ri[q] * rj[q];
-        acc = ri[j] - ((a0 + a1) + (a2 + a3));
-        if (lane == j) L(D::oRED) = acc;
+    static_assert(NU % 4 == 0, "panel width 4");
+    bool ok = true;
+    for (int J = 0; J < NU; J += 4) {
+      const bool own = lane >= J && lane < NZ;
+      const int li = own ? lane : J + 3;      // idle lanes shadow a valid row; their results are never stored
+      const double *ri = M + tri(li);
+      const double *r0 = M + tri(J), *r1 = M + tri(J + 1), *r2 = M + tri(J + 2), *r3 = M + tri(J + 3);
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll 4
+      for (int q = 0; q < J; ++q) {
+        const double x = ri[q];
+        d0 += x * r0[q]; d1 += x * r1[q]; d2 += x * r2[q]; d3 += x * r3[q];
       }
-      CMPC_SYNC();
-      const double piv = L(D::oRED);
-      if (!(piv > 1e-14)) return false;
-      if (lane >= j && lane < NZ) {
-        const double dj = sqrt(piv);
-        M[tri(lane) + j] = (lane == j) ? dj : acc / dj;
+      // entries above the diagonal of rows J..J+2 do not exist: read a harmless in-row word instead
+      const int c1i = (li >= J + 1) ? J + 1 : J, c2i = (li >= J + 2) ? J + 2 : J, c3i = (li >= J + 3) ? J + 3 : J;
+      double a0 = ri[J] - d0, a1 = ri[c1i] - d1, a2 = ri[c2i] - d2, a3 = ri[c3i] - d3;
+      // column J
+      const double p0 = CMPC_BCAST(a0, J);
+      ok = ok && (p0 > 1e-14);
+      const double s0 = sqrt(p0), i0 = 1.0 / s0;
+      const double l0 = (lane == J) ? s0 : a0 * i0;
+      // column J+1
+      a1 -= l0 * CMPC_BCAST(l0, J + 1);
+      const double p1 = CMPC_BCAST(a1, J + 1);
+      ok = ok && (p1 > 1e-14);
+      const double s1 = sqrt(p1), i1 = 1.0 / s1;
+      const double l1 = (lane == J + 1) ? s1 : a1 * i1;
+      // column J+2
+      a2 -= l0 * CMPC_BCAST(l0, J + 2) + l1 * CMPC_BCAST(l1, J + 2);
+      const double p2 = CMPC_BCAST(a2, J + 2);
+      ok = ok && (p2 > 1e-14);
+      const double s2 = sqrt(p2), i2 = 1.0 / s2;
+      const double l2 = (lane == J + 2) ? s2 : a2 * i2;
+      // column J+3
+      a3 -= l0 * CMPC_BCAST(l0, J + 3) + l1 * CMPC_BCAST(l1, J + 3) + l2 * CMPC_BCAST(l2, J + 3);
+      const double p3 = CMPC_BCAST(a3, J + 3);
+      ok = ok && (p3 > 1e-14);
+      const double s3 = sqrt(p3), i3 = 1.0 / s3;
+      const double l3 = (lane == J + 3) ? s3 : a3 * i3;
+      if (!ok) return false;                   // pivots are wave-uniform
+      if (own) {
+        double *wi = M + tri(lane) + J;
+        wi[0] = l0;
+        if (lane >= J + 1) wi[1] = l1;
+        if (lane >= J + 2) wi[2] = l2;
+        if (lane >= J + 3) wi[3] = l3;
       }
       CMPC_SYNC();
     }
+    CMPC_TICK(8);
     if (k == 0) return true;                 // x_0 is data: no cost-to-go needed
-    // P_k = M_xx - Ls Ls'   (row owner i, all columns; split the q-range over the two lane halves)
-    // lanes 0..31 subtract their half of the q-sum in place (columns >= NU of their own row, which
-    // nobody reads here); lanes 32..63 park the other half in the T region (NXA*PS <= NXA*TS).
-    static_assert(NXA * D::PS <= NXA * D::TS, "T region too small for the Schur partials");
+    // P_k = M_xx - Ls Ls' : lane (ii, half) keeps row ii of Ls in registers and owns the columns of
+    // its half of [0, ii]; every (ii, c) entry is produced by exactly one lane and written to both
+    // triangles of P.
     {
       const int hsel = lane >> 5;
-      const int q0 = hsel ? NU / 2 : 0;
-      static_assert((NU / 2) % 4 == 0, "q-range split assumes NU % 8 == 0");
       for (int ii = (lane & 31); ii < NXA; ii += 32) {
-        double *ri = M + tri(NU + ii);
-        for (int c = 0; c <= ii; ++c) {
+        const double *ri = M + tri(NU + ii);
+        double rrow[NU];
+#pragma unroll
+        for (int q = 0; q < NU; ++q) rrow[q] = ri[q];
+        const int mid = (ii + 1) / 2;
+        const int cb = hsel ? mid : 0, ce = hsel ? ii + 1 : mid;
+        for (int c = cb; c < ce; ++c) {
           const double *rc = M + tri(NU + c);
           double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-          for (int q = 0; q < NU / 2; q += 4) {
-            a0 += ri[q0 + q] * rc[q0 + q]; a1 += ri[q0 + q + 1] * rc[q0 + q + 1];
-            a2 += ri[q0 + q + 2] * rc[q0 + q + 2]; a3 += ri[q0 + q + 3] * rc[q0 + q + 3];
+          for (int q = 0; q < NU; q += 4) {
+            a0 += rrow[q] * rc[q]; a1 += rrow[q + 1] * rc[q + 1];
+            a2 += rrow[q + 2] * rc[q + 2]; a3 += rrow[q + 3] * rc[q + 3];
           }
-          const double a = (a0 + a1) + (a2 + a3);
-          if (hsel) L(D::oT + ii * D::PS + c) = a; else ri[NU + c] -= a;
+          const double v = ri[NU + c] - ((a0 + a1) + (a2 + a3));
+          L(D::oP + ii * D::PS + c) = v;
+          L(D::oP + c * D::PS + ii) = v;
+          CMPC_SCHED_FENCE();
         }
       }
     }
     CMPC_SYNC();
-    for (int e = lane; e < NXA * NXA; e += 64) {
-      const int i = e / NXA, c = e % NXA;
-      const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
-      L(D::oP + i * D::PS + c) = M[tri(NU + hi) + NU + lo] - L(D::oT + hi * D::PS + lo);
-    }
-    CMPC_SYNC();
+    CMPC_TICK(9);
     return true;
   }
 
@@ -755,7 +811,9 @@ template <int NV> struct Solver {
         if (lane < NXA) L(D::oBV + lane) = 0.0;
         CMPC_SYNC();
       }
+      CMPC_TICK(11);
       stage_ineq(k, x0n2);
+      CMPC_TICK(12);
       // barrier weights (W2 holds the activity flag on entry)
       for (int r = lane; r < NI; r += 64) {
         const bool act = L(D::oW2 + r) != 0.0;
@@ -857,6 +915,7 @@ template <int NV> struct Solver {
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void vector_sweeps(double mu) {
     const double m = rec[20];
+    CMPC_SYNC_GLOBAL();                       // P_k of the matrix sweep is re-read with another lane mapping
     {
       const double *st = stage(N);
       if (lane < NXA) {
@@ -878,14 +937,21 @@ template <int NV> struct Solver {
         L(D::oTV + lane) = a;
       }
       CMPC_SYNC();
-      // l = L^-1 m_u  (column-oriented forward substitution)
-      for (int j = 0; j < NU; ++j) {
-        if (lane == j) L(D::oTV + j) = L(D::oTV + j) / L(D::oM + j * D::LS + j);
-        CMPC_SYNC();
-        if (lane > j && lane < NU) L(D::oTV + lane) -= L(D::oM + lane * D::LS + j) * L(D::oTV + j);
-        CMPC_SYNC();
+      // l = L^-1 m_u: column-oriented forward substitution, right-hand side in a register per lane,
+      // l_j broadcast by readlane (no LDS round trip in the 32-step dependent chain)
+      {
+        const int li = (lane < NU) ? lane : NU - 1;
+        double mreg = L(D::oTV + li);
+        const double dinv = 1.0 / L(D::oM + li * D::LS + li);
+#pragma unroll 8
+        for (int j = 0; j < NU; ++j) {
+          const double lj = CMPC_BCAST(mreg * dinv, j);
+          const double lij = L(D::oM + li * D::LS + j);
+          if (lane > j) mreg -= lij * lj;
+        }
+        if (lane < NU) { L(D::oTV + lane) = mreg * dinv; st[D::gL + lane] = mreg * dinv; }
       }
-      if (lane < NU) st[D::gL + lane] = L(D::oTV + lane);
+      CMPC_SYNC();
       if (lane < NXA) {
         double a = L(D::oTV + NU + lane);
         for (int q = 0; q < NU; ++q) a -= L(D::oM + (NU + lane) * D::LS + q) * L(D::oTV + q);
@@ -907,13 +973,18 @@ template <int NV> struct Solver {
         L(D::oTV + lane) = -a;
       }
       CMPC_SYNC();
-      for (int j = NU - 1; j >= 0; --j) {      // L' du = t
-        if (lane == j) L(D::oTV + j) = L(D::oTV + j) / L(D::oM + j * D::LS + j);
-        CMPC_SYNC();
-        if (lane < j) L(D::oTV + lane) -= L(D::oM + j * D::LS + lane) * L(D::oTV + j);
-        CMPC_SYNC();
+      {                                        // L' du = t, same scheme backwards
+        const int li = (lane < NU) ? lane : NU - 1;
+        double treg = L(D::oTV + li);
+        const double dinv = 1.0 / L(D::oM + li * D::LS + li);
+#pragma unroll 8
+        for (int j = NU - 1; j >= 0; --j) {
+          const double dj = CMPC_BCAST(treg * dinv, j);
+          const double lji = L(D::oM + j * D::LS + li);
+          if (lane < j) treg -= lji * dj;
+        }
+        if (lane < NU) { gdu[(size_t)k * NU + lane] = treg * dinv; L(D::oUK + lane) = treg * dinv; }
       }
-      if (lane < NU) { gdu[(size_t)k * NU + lane] = L(D::oTV + lane); L(D::oUK + lane) = L(D::oTV + lane); }
       CMPC_SYNC();
       // dx+ = b + [B A] (du, dx)
       if (lane < NXA) {
@@ -1004,6 +1075,7 @@ template <int NV> struct Solver {
   }
 
   CMPC_DEV void apply_step(double mu, double ap, double ad) {
+    CMPC_SYNC_GLOBAL();                       // directions were written with a per-stage lane mapping
     for (int e = lane; e < (N + 1) * NXA; e += 64) {
       if (e >= NXA) {
         gx[e] += ap * gdx[e];
@@ -1020,7 +1092,7 @@ template <int NV> struct Solver {
         gsl[e] = s; gz[e] = fmin(fmax(z, lo), hi);
       }
     }
-    CMPC_SYNC();
+    CMPC_SYNC_GLOBAL();
   }
 
   // Initial point: warm start or hover forces; x_0 from the record; carried f_z states.
@@ -1042,12 +1114,12 @@ template <int NV> struct Solver {
       }
       gu[e] = v; gupx[e] = up;
     }
-    CMPC_SYNC();
+    CMPC_SYNC_GLOBAL();
     for (int e = lane; e < N * NF; e += 64) {
       const int k = e / NF + 1, j = e % NF;
       gx[(size_t)k * NXA + CMPC_NX + j] = gu[(size_t)(k - 1) * NU + 3 * j + 2];
     }
-    CMPC_SYNC();
+    CMPC_SYNC_GLOBAL();
   }
 
   CMPC_DEV void init_slacks(double mu, double x0n2) {
@@ -1073,6 +1145,7 @@ template <int NV> struct Solver {
       }
       CMPC_SYNC();
     }
+    CMPC_SYNC_GLOBAL();
   }
 
   // ---------------------------------------------------------------------------------------
@@ -1158,7 +1231,7 @@ template <int NV> struct Solver {
     }
 #if defined(CMPC_PROFILE) && !defined(CMPC_HOST_EMU)
     if (lane == 0 && ka.prof)
-      for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);
+      for (int i = 0; i < 16; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);
 #endif
     CMPC_SYNC();
   }

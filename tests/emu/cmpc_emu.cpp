@@ -17,6 +17,18 @@ static pthread_barrier_t emu_barrier;
 #define CMPC_DEVN
 #define CMPC_LANE (emu_lane_id)
 #define CMPC_SYNC() pthread_barrier_wait(&emu_barrier)
+#define CMPC_SYNC_GLOBAL() pthread_barrier_wait(&emu_barrier)
+// broadcast of lane `src`'s value: through a shared slot, two barriers
+static double emu_bcast_slot;
+static inline double emu_bcast(double v, int src) {
+  if (emu_lane_id == src) emu_bcast_slot = v;
+  pthread_barrier_wait(&emu_barrier);
+  double r = emu_bcast_slot;
+  pthread_barrier_wait(&emu_barrier);
+  return r;
+}
+#define CMPC_BCAST(v, src) emu_bcast((v), (src))
+#define CMPC_SCHED_FENCE() do { } while (0)
 
 #include "../../online-non-linear-centroidal-mpc-with-stability-guarantees-for-robust-locomotion-of-legged-robots-_amd/csrc/cmpc_kernel.hpp"
 
