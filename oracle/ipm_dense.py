@@ -23,7 +23,7 @@ def _inertia_ok(K, nw, ne):
 
 
 def solve(spec, par, w0=None, u_prox=None, tol=1e-9, max_iter=300, verbose=False,
-          mu0=0.1, hessian="exact", linesearch=True):
+          mu0=100.0, hessian="exact", linesearch=True):
     """Returns dict(w, iters, kkt, status, lam, z, s).  status 0 = converged."""
     N = spec.N
     nw = nlp.NX * (N + 1) + spec.nu * N
@@ -74,7 +74,7 @@ def solve(spec, par, w0=None, u_prox=None, tol=1e-9, max_iter=300, verbose=False
             status = 0
             break
         while mu > tol / 10 and max(e_d, e_p, np.abs(comp - mu).max() / sd) < 10 * mu:
-            mu = max(tol / 10, min(0.2 * mu, mu ** 1.5))
+            mu = max(tol / 10, min(0.1 * mu, mu ** 1.5))
         Sig = z / s
         Hb = H + Jg.T @ (Sig[:, None] * Jg)
         reg = 0.0
