@@ -37,6 +37,21 @@ def algorithmic_bytes(N, nu, warm):
     return 8 * ((19 * N + 22 + 2) + (nu * N + 20 * (N + 1)) * (1 + int(warm))) + 16
 
 
+def measured_traffic(workload, batch, N):
+    """HBM bytes per launch from the committed PMC runs (profiles/*traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc passes of this same command), or None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("batch") == batch and d.get("N") == N:
+            best = (d["hbm_bytes_per_launch"], os.path.basename(path))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +123,7 @@ def main():
     achieved = b_io * (hi - lo) / (last_ms * 1e-3) / 1e9             # GB/s of algorithmic bytes, this rank
     flops = 3.0e6 * mean_iters * (hi - lo) / (last_ms * 1e-3) / 1e12  # ~3 Mflop per Newton/Riccati step
 
+    traffic = measured_traffic(args.workload, args.batch, spec.N)
     result = {
         "metric": "centroidal-MPC solves/sec, N=20 horizon",
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -119,7 +135,8 @@ def main():
                    "converged_fraction": conv_frac, "mean_iterations": mean_iters,
                    "parallelism": f"batch-sharded x{world}, final all-gather of (x1,u0,status)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                     "traffic_source": traffic[1] if traffic else None,
                      "kernel": "cmpc_solve_kernel<4>", "kernel_ms": last_ms,
                      "algorithmic_bytes_per_solve": b_io,
                      "note": "latency/FP64-issue bound in practice (SURVEY 8d): see fp64_tflops",
