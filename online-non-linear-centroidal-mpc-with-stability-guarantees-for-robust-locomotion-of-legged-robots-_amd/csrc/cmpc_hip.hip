@@ -101,10 +101,6 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   if (!out) return fail(nullptr, "cmpc_create: null out pointer");
   *out = nullptr;
   if (!spec_ok(spec)) return fail(nullptr, "cmpc_create: invalid spec (N in [1,64], nv in {4,8})");
-  // The wave-per-instance kernel maps one lane to one row of the (nu+nx)^2 stage block; with 8-vertex
-  // patches that block has 92 rows (> 64 lanes).  Until the two-rows-per-lane variant lands the GPU
-  // path serves the reference's 4-vertex feet only ("next").
-  if (spec->nv != 4) return fail(nullptr, "cmpc_create: nv = 8 is not supported by the GPU path yet");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "cmpc_create: no HIP device");
   if (device < 0 || device >= ndev) return fail(nullptr, "cmpc_create: bad device index");

@@ -98,6 +98,7 @@ template <int NV> struct Dims {
   static constexpr int NZ = NU + NXA;
   static constexpr int NI = 15 + 10 * NV;
   static constexpr int NTRI = NZ * (NZ + 1) / 2;
+  static constexpr int NH = (NZ + 63) / 64;   // rows / columns of the stage block owned by one lane
   static constexpr int PS = NXA + 1;          // odd row strides: conflict-free column access
   static constexpr int LS = NU + 1;
   static constexpr int TH = (NZ + 1) / 2;     // columns per half of T = P [B A]
@@ -163,7 +164,7 @@ CMPC_DEV int tri(int i) { return i * (i + 1) / 2; }
 
 template <int NV> struct Solver {
   using D = Dims<NV>;
-  static constexpr int NF = D::NF, NU = D::NU, NXA = D::NXA, NZ = D::NZ, NI = D::NI;
+  static constexpr int NF = D::NF, NU = D::NU, NXA = D::NXA, NZ = D::NZ, NI = D::NI, NH = D::NH;
 
   const KArgs &ka;
   const cmpc_spec &sp;
@@ -174,8 +175,8 @@ template <int NV> struct Solver {
   // global iterate arrays
   double *gx, *glam, *gdx, *glamn, *gu, *gdu, *gupx, *gsl, *gz, *gds, *gdz;
   // per-lane column list of [B A]: rows / coefficients (id, h0, h1, h2, sp1, sp2)
-  int lr[6];
-  double lg[6];
+  int lr[NH][6];
+  double lg[NH][6];
   long long tprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
   bool dbg_on = false;
 
@@ -360,26 +361,32 @@ template <int NV> struct Solver {
   // Column list of [B A] for this lane's column (lane < NZ): id, 3 h-rows, 2 specials.
   CMPC_DEV void build_list(const double *gh, double gl, double gr, double m) {
     const double d = sp.delta;
-    for (int n = 0; n < 6; ++n) { lr[n] = 0; lg[n] = 0.0; }
-    if (lane >= NZ) return;
-    const int col = lane;
-    lr[1] = 6; lr[2] = 7; lr[3] = 8;
-    lg[1] = gh[col]; lg[2] = gh[NZ + col]; lg[3] = gh[2 * NZ + col];
-    if (col < 6 * NV) {
-      const int v = col / 3, a = col % 3, f = v / NV;
-      lr[4] = 3 + a; lg[4] = d * (f ? gr : gl) / m;
-      if (a == 2) { lr[5] = 20 + v; lg[5] = 1.0; }
-    } else if (col < 6 * NV + 6) {
-      const int f = (col - 6 * NV) / 3, a = (col - 6 * NV) % 3;
-      lr[4] = 13 + 4 * f + a; lg[4] = d * (1 - (f ? gr : gl));
-    } else if (col < NU) {
-      const int f = col - 6 * NV - 6;
-      lr[4] = 12 + 4 * f; lg[4] = d * (1 - (f ? gr : gl));
-    } else {
-      const int s = col - NU;
-      if (s < CMPC_NX) { lr[0] = s; lg[0] = 1.0; }
-      if (s < 3) { lr[4] = 9 + s; lg[4] = d * sp.k1 / m; }
-      else if (s < 6) { lr[4] = s - 3; lg[4] = d; lr[5] = 9 + s - 3; lg[5] = d / m; }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      int *r = lr[h];
+      double *g = lg[h];
+#pragma unroll
+      for (int n = 0; n < 6; ++n) { r[n] = 0; g[n] = 0.0; }
+      const int col = lane + 64 * h;
+      if (col >= NZ) continue;
+      r[1] = 6; r[2] = 7; r[3] = 8;
+      g[1] = gh[col]; g[2] = gh[NZ + col]; g[3] = gh[2 * NZ + col];
+      if (col < 6 * NV) {
+        const int v = col / 3, a = col % 3, f = v / NV;
+        r[4] = 3 + a; g[4] = d * (f ? gr : gl) / m;
+        if (a == 2) { r[5] = 20 + v; g[5] = 1.0; }
+      } else if (col < 6 * NV + 6) {
+        const int f = (col - 6 * NV) / 3, a = (col - 6 * NV) % 3;
+        r[4] = 13 + 4 * f + a; g[4] = d * (1 - (f ? gr : gl));
+      } else if (col < NU) {
+        const int f = col - 6 * NV - 6;
+        r[4] = 12 + 4 * f; g[4] = d * (1 - (f ? gr : gl));
+      } else {
+        const int s = col - NU;
+        if (s < CMPC_NX) { r[0] = s; g[0] = 1.0; }
+        if (s < 3) { r[4] = 9 + s; g[4] = d * sp.k1 / m; }
+        else if (s < 6) { r[4] = s - 3; g[4] = d; r[5] = 9 + s - 3; g[5] = d / m; }
+      }
     }
   }
 
@@ -515,8 +522,11 @@ template <int NV> struct Solver {
   // Row `lane` of the Lagrangian Hessian + barrier terms into the packed lower triangle M.
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void build_H(int k, double reg) {
-    if (lane >= NZ) return;
-    const int i = lane;
+#pragma unroll 1
+    for (int h_ = 0; h_ < NH; ++h_) build_H_row(k, reg, lane + 64 * h_);
+  }
+  CMPC_DEV void build_H_row(int k, double reg, const int i) {
+    if (i >= NZ) return;
     double *row = &L(D::oM + tri(i));
     for (int j = 0; j <= i; ++j) row[j] = 0.0;
     const double m = L(D::oHDR + 20), muf = L(D::oHDR + 21);
@@ -651,48 +661,55 @@ template <int NV> struct Solver {
     // small enough (<= 2 x 14 doubles live) that the allocator does not serialise the reads.
     constexpr int QT = (NXA % 2 == 0) ? NXA / 2 : NXA;          // rows of T per tile
     constexpr int CT = 10;                                      // columns of M per tile
-    static_assert(D::TH % CT == 0 || D::TH < CT * 5, "tile bookkeeping");
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       const int c0 = half * D::TH, c1 = (c0 + D::TH < NZ) ? c0 + D::TH : NZ;
-      if (lane >= c0 && lane < c1) {           // column `lane` of T = P [B A]
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {           // column of T = P [B A] owned by this lane in this half
+        const int col = lane + 64 * h;
+        if (col >= c0 && col < c1) {
 #pragma unroll 1
-        for (int q0 = 0; q0 < NXA; q0 += QT) {
-          double acc[QT];
+          for (int q0 = 0; q0 < NXA; q0 += QT) {
+            double acc[QT];
 #pragma unroll
-          for (int q = 0; q < QT; ++q) acc[q] = 0.0;
+            for (int q = 0; q < QT; ++q) acc[q] = 0.0;
 #pragma unroll
-          for (int n = 0; n < 6; ++n) {
-            const double g = lg[n];
-            const double *pc = &L(D::oP + q0 * D::PS + lr[n]);
+            for (int n = 0; n < 6; ++n) {
+              const double g = lg[h][n];
+              const double *pc = &L(D::oP + q0 * D::PS + lr[h][n]);
 #pragma unroll
-            for (int q = 0; q < QT; ++q) acc[q] += g * pc[q * D::PS];
+              for (int q = 0; q < QT; ++q) acc[q] += g * pc[q * D::PS];
+            }
+            double *tc = &L(D::oT + q0 * D::TS + (col - c0));
+#pragma unroll
+            for (int q = 0; q < QT; ++q) tc[q * D::TS] = acc[q];
           }
-          double *tc = &L(D::oT + q0 * D::TS + (lane - c0));
-#pragma unroll
-          for (int q = 0; q < QT; ++q) tc[q * D::TS] = acc[q];
         }
       }
       CMPC_SYNC();
       CMPC_TICK(10);
-      if (lane >= c0 && lane < NZ) {           // row `lane` of M, columns c0 .. min(lane, c1-1)
-        const int iend = ((lane < c1 - 1) ? lane : c1 - 1) - c0;   // last column, relative to c0
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {           // owned row of M, columns c0 .. min(row, c1-1)
+        const int rowi = lane + 64 * h;
+        if (rowi >= c0 && rowi < NZ) {
+          const int iend = ((rowi < c1 - 1) ? rowi : c1 - 1) - c0;   // last column, relative to c0
 #pragma unroll 1
-        for (int i0 = 0; i0 <= iend; i0 += CT) {
-          double acc[CT];
+          for (int i0 = 0; i0 <= iend; i0 += CT) {
+            double acc[CT];
 #pragma unroll
-          for (int i = 0; i < CT; ++i) acc[i] = 0.0;
+            for (int i = 0; i < CT; ++i) acc[i] = 0.0;
 #pragma unroll
-          for (int n = 0; n < 6; ++n) {
-            const double g = lg[n];
-            const double *tr = &L(D::oT + lr[n] * D::TS + i0);
+            for (int n = 0; n < 6; ++n) {
+              const double g = lg[h][n];
+              const double *tr = &L(D::oT + lr[h][n] * D::TS + i0);
 #pragma unroll
-            for (int i = 0; i < CT; ++i) acc[i] += g * tr[i];   // tail columns read valid LDS, results unused
+              for (int i = 0; i < CT; ++i) acc[i] += g * tr[i];   // tail columns read valid LDS, results unused
+            }
+            double *row = &L(D::oM + tri(rowi) + c0 + i0);
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+              if (i0 + i <= iend) row[i] += acc[i];
           }
-          double *row = &L(D::oM + tri(lane) + c0 + i0);
-#pragma unroll
-          for (int i = 0; i < CT; ++i)
-            if (i0 + i <= iend) row[i] += acc[i];
         }
       }
       CMPC_SYNC();
@@ -706,51 +723,73 @@ template <int NV> struct Solver {
   CMPC_DEV bool factor_stage(int k) {
     double *M = &L(D::oM);
     static_assert(NU % 4 == 0, "panel width 4");
+    static_assert(NU <= 64, "panel rows must live in the first row set");
     bool ok = true;
     for (int J = 0; J < NU; J += 4) {
-      const bool own = lane >= J && lane < NZ;
-      const int li = own ? lane : J + 3;      // idle lanes shadow a valid row; their results are never stored
-      const double *ri = M + tri(li);
       const double *r0 = M + tri(J), *r1 = M + tri(J + 1), *r2 = M + tri(J + 2), *r3 = M + tri(J + 3);
-      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+      double l0v[NH], l1v[NH], l2v[NH], l3v[NH];
+      double t10 = 0, t20 = 0, t21 = 0, t30 = 0, t31 = 0, t32 = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int rowi = lane + 64 * h;
+        const bool own = rowi >= J && rowi < NZ;
+        const int li = own ? rowi : J + 3;    // idle lanes shadow a valid row; their results are never stored
+        const double *ri = M + tri(li);
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll 4
-      for (int q = 0; q < J; ++q) {
-        const double x = ri[q];
-        d0 += x * r0[q]; d1 += x * r1[q]; d2 += x * r2[q]; d3 += x * r3[q];
+        for (int q = 0; q < J; ++q) {
+          const double x = ri[q];
+          d0 += x * r0[q]; d1 += x * r1[q]; d2 += x * r2[q]; d3 += x * r3[q];
+        }
+        // entries above the diagonal of rows J..J+2 do not exist: read a harmless in-row word instead
+        const int c1i = (li >= J + 1) ? J + 1 : J, c2i = (li >= J + 2) ? J + 2 : J, c3i = (li >= J + 3) ? J + 3 : J;
+        double a0 = ri[J] - d0, a1 = ri[c1i] - d1, a2 = ri[c2i] - d2, a3 = ri[c3i] - d3;
+        if (h == 0) {                          // the panel itself: pivots and multipliers by readlane
+          const double p0 = CMPC_BCAST(a0, J);
+          ok = ok && (p0 > 1e-14);
+          const double s0 = sqrt(p0); i0 = 1.0 / s0;
+          const double l0 = (lane == J) ? s0 : a0 * i0;
+          t10 = CMPC_BCAST(l0, J + 1);
+          a1 -= l0 * t10;
+          const double p1 = CMPC_BCAST(a1, J + 1);
+          ok = ok && (p1 > 1e-14);
+          const double s1 = sqrt(p1); i1 = 1.0 / s1;
+          const double l1 = (lane == J + 1) ? s1 : a1 * i1;
+          t20 = CMPC_BCAST(l0, J + 2); t21 = CMPC_BCAST(l1, J + 2);
+          a2 -= l0 * t20 + l1 * t21;
+          const double p2 = CMPC_BCAST(a2, J + 2);
+          ok = ok && (p2 > 1e-14);
+          const double s2 = sqrt(p2); i2 = 1.0 / s2;
+          const double l2 = (lane == J + 2) ? s2 : a2 * i2;
+          t30 = CMPC_BCAST(l0, J + 3); t31 = CMPC_BCAST(l1, J + 3); t32 = CMPC_BCAST(l2, J + 3);
+          a3 -= l0 * t30 + l1 * t31 + l2 * t32;
+          const double p3 = CMPC_BCAST(a3, J + 3);
+          ok = ok && (p3 > 1e-14);
+          const double s3 = sqrt(p3); i3 = 1.0 / s3;
+          const double l3 = (lane == J + 3) ? s3 : a3 * i3;
+          l0v[0] = l0; l1v[0] = l1; l2v[0] = l2; l3v[0] = l3;
+        } else {                               // rows below the panel reuse the broadcast multipliers
+          const double l0 = a0 * i0;
+          a1 -= l0 * t10;
+          const double l1 = a1 * i1;
+          a2 -= l0 * t20 + l1 * t21;
+          const double l2 = a2 * i2;
+          a3 -= l0 * t30 + l1 * t31 + l2 * t32;
+          const double l3 = a3 * i3;
+          l0v[h] = l0; l1v[h] = l1; l2v[h] = l2; l3v[h] = l3;
+        }
       }
-      // entries above the diagonal of rows J..J+2 do not exist: read a harmless in-row word instead
-      const int c1i = (li >= J + 1) ? J + 1 : J, c2i = (li >= J + 2) ? J + 2 : J, c3i = (li >= J + 3) ? J + 3 : J;
-      double a0 = ri[J] - d0, a1 = ri[c1i] - d1, a2 = ri[c2i] - d2, a3 = ri[c3i] - d3;
-      // column J
-      const double p0 = CMPC_BCAST(a0, J);
-      ok = ok && (p0 > 1e-14);
-      const double s0 = sqrt(p0), i0 = 1.0 / s0;
-      const double l0 = (lane == J) ? s0 : a0 * i0;
-      // column J+1
-      a1 -= l0 * CMPC_BCAST(l0, J + 1);
-      const double p1 = CMPC_BCAST(a1, J + 1);
-      ok = ok && (p1 > 1e-14);
-      const double s1 = sqrt(p1), i1 = 1.0 / s1;
-      const double l1 = (lane == J + 1) ? s1 : a1 * i1;
-      // column J+2
-      a2 -= l0 * CMPC_BCAST(l0, J + 2) + l1 * CMPC_BCAST(l1, J + 2);
-      const double p2 = CMPC_BCAST(a2, J + 2);
-      ok = ok && (p2 > 1e-14);
-      const double s2 = sqrt(p2), i2 = 1.0 / s2;
-      const double l2 = (lane == J + 2) ? s2 : a2 * i2;
-      // column J+3
-      a3 -= l0 * CMPC_BCAST(l0, J + 3) + l1 * CMPC_BCAST(l1, J + 3) + l2 * CMPC_BCAST(l2, J + 3);
-      const double p3 = CMPC_BCAST(a3, J + 3);
-      ok = ok && (p3 > 1e-14);
-      const double s3 = sqrt(p3), i3 = 1.0 / s3;
-      const double l3 = (lane == J + 3) ? s3 : a3 * i3;
       if (!ok) return false;                   // pivots are wave-uniform
-      if (own) {
-        double *wi = M + tri(lane) + J;
-        wi[0] = l0;
-        if (lane >= J + 1) wi[1] = l1;
-        if (lane >= J + 2) wi[2] = l2;
-        if (lane >= J + 3) wi[3] = l3;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int rowi = lane + 64 * h;
+        if (rowi >= J && rowi < NZ) {
+          double *wi = M + tri(rowi) + J;
+          wi[0] = l0v[h];
+          if (rowi >= J + 1) wi[1] = l1v[h];
+          if (rowi >= J + 2) wi[2] = l2v[h];
+          if (rowi >= J + 3) wi[3] = l3v[h];
+        }
       }
       CMPC_SYNC();
     }
@@ -862,8 +901,10 @@ template <int NV> struct Solver {
       CMPC_SYNC();
       build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
       double *st = stage(k);
-      if (lane < NZ) {
-        const int col = lane;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int col = lane + 64 * h;
+        if (col >= NZ) continue;
         const double ho = cost_grad(k, col);
         double jw[3];
 #pragma unroll 1
@@ -872,7 +913,7 @@ template <int NV> struct Solver {
           if (t == 0) jw[0] = v; else if (t == 1) jw[1] = v; else jw[2] = v;
         }
         double r = ho + jw[0];
-        if (k < N) for (int n = 0; n < 6; ++n) r += lg[n] * L(D::oLAMN + lr[n]);
+        if (k < N) for (int n = 0; n < 6; ++n) r += lg[h][n] * L(D::oLAMN + lr[h][n]);
         if (col >= NU) r -= L(D::oLAMK + col - NU);
         const bool is_var = (col < NU) ? (k < N) : (k >= 1);
         if (is_var) er.e_d = fmax(er.e_d, fabs(r));
@@ -978,10 +1019,13 @@ template <int NV> struct Solver {
       build_list(&L(D::oGH), L(D::oSR + 17), L(D::oSR + 18), m);
       if (lane < NXA) L(D::oXN1 + lane) = L(D::oPC + lane) + st[D::gPB + lane];
       CMPC_SYNC();
-      if (lane < NZ) {
-        double a = st[D::gH0 + lane] + mu * st[D::gH1 + lane];
-        for (int n = 0; n < 6; ++n) a += lg[n] * L(D::oXN1 + lr[n]);
-        L(D::oTV + lane) = a;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int col = lane + 64 * h;
+        if (col >= NZ) continue;
+        double a = st[D::gH0 + col] + mu * st[D::gH1 + col];
+        for (int n = 0; n < 6; ++n) a += lg[h][n] * L(D::oXN1 + lr[h][n]);
+        L(D::oTV + col) = a;
       }
       CMPC_SYNC();
       // l = L^-1 m_u: column-oriented forward substitution, right-hand side in a register per lane,
@@ -1134,7 +1178,7 @@ template <int NV> struct Solver {
       if (lane < 19) L(D::oSR + lane) = (k < N) ? rec[24 + 19 * k + lane] : 0.0;
       CMPC_SYNC();
       double part = 0.0;
-      if (lane < NZ) part = st[D::gAL + lane] * ((lane < NU) ? L(D::oUK + lane) : L(D::oXN1 + lane - NU));
+      for (int c = lane; c < NZ; c += 64) part += st[D::gAL + c] * ((c < NU) ? L(D::oUK + c) : L(D::oXN1 + c - NU));
       const double ldot = red_sum(part);
       for (int r = lane; r < NI; r += 64) {
         const double s = gsl[(size_t)k * NI + r], z = gz[(size_t)k * NI + r], g = st[D::gG + r];

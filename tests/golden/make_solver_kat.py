@@ -17,7 +17,7 @@ for name, B, N in (("perturbed", 6, 20), ("payload", 4, 20), ("randomized", 4, 2
     spec, rec = wl.make_workload(name, B=B, N=N, scale=0.5)
     cs = ol.default_spec(N=spec.N, nv=spec.nv, tol=1e-10, max_iter=300, k1=spec.k1, k2=spec.k2)
     sol, st, it, kkt = ol.solve_batch(cs, rec)
-    keep = (st == 0) & (it <= 40)        # well-conditioned instances only: hard ones are path dependent at 1e-6
+    keep = (st == 0) & (it <= 30)        # well-conditioned instances only: hard ones are path dependent at 1e-6
     out = os.path.join(HERE, f"solver_kat_{name}_N{N}.npz")
     np.savez_compressed(out, records=rec[keep], solutions=sol[keep], k1=spec.k1, k2=spec.k2, N=N, nv=spec.nv)
     print(out, int(keep.sum()), "instances, iterations", it[keep])

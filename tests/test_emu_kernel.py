@@ -42,7 +42,6 @@ def test_kernel_source_matches_oracle(emu, oracle, name, N):
     assert rel_inf(got, ref).max() < 1e-9
 
 
-@pytest.mark.xfail(reason="8-vertex patches need two rows per lane (92 > 64); scheduled, see DESIGN.md", strict=False)
 def test_kernel_source_eight_vertex_patch(emu, oracle):
     spec, rec = wl.make_workload("long_horizon", B=1, N=2)
     cs = oracle_spec(oracle, spec)

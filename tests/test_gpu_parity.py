@@ -36,7 +36,8 @@ def _solve(gpu, spec, rec, warm=None):
 
 
 @pytest.mark.parametrize("name,B,N", [("perturbed", 256, 20), ("payload", 512, 20), ("randomized", 512, 20),
-                                        ("perturbed", 128, 10), ("perturbed", 64, 3), ("perturbed", 32, 40)])
+                                        ("perturbed", 128, 10), ("perturbed", 64, 3), ("perturbed", 32, 40),
+                                        ("long_horizon", 64, 10), ("long_horizon", 48, 40)])
 def test_parity_with_oracle(gpu, oracle, name, B, N):
     spec, rec = wl.make_workload(name, B=B, N=N)
     if N > 20:
