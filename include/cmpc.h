@@ -93,6 +93,29 @@ int cmpc_solve_batch(cmpc_handle *h, int32_t B, const double *params, const doub
  * HIP events on the launch stream; synchronises that stream. */
 int cmpc_last_kernel_ms(cmpc_handle *h, float *ms);
 
+/*
+ * Batched parameter builder = front half of centroidal_mpc.solve (code/centroidal_mpc_vertices.py:482-600)
+ * and the planner lookups behind it (code/footstep_planner_vertices.py:82-147) as one gather kernel.
+ * The per-tick tables (host arrays, T rows each) are uploaded once:
+ *   com_tab  T x 9   pos(3) vel(3) acc(3) of the CoM reference          (:64-74, :567-577)
+ *   pose_l/r T x 6   nominal contact poses [ang(3), pos(3)]              (:77-84,  :581-584)
+ *   gl/gr    T       contact flags at every tick                         (:515-534)
+ *   cur_l/r  T x 3   foot positions written into x0 at tick t            (:493-509)
+ */
+typedef struct cmpc_tables cmpc_tables;
+int cmpc_tables_create(int device, int32_t T, const double *com_tab, const double *pose_l, const double *pose_r,
+                       const double *gl, const double *gr, const double *cur_l, const double *cur_r,
+                       cmpc_tables **out);
+int cmpc_tables_destroy(cmpc_tables *tb);
+/*
+ * records[b] for b < B from tick t[b] and the measured state
+ *   state[b] = [com(3) dcom(3) hw(3) theta_hat(3) yaw_l yaw_r mass mu]   (16 doubles, device)
+ * t (int32, device) must satisfy 0 <= t[b] and t[b] + (N+1)*rate < T (checked on the device: an
+ * offending record is filled with NaN).  Asynchronous on `stream`.
+ */
+int cmpc_build_records(const cmpc_tables *tb, int32_t N, int32_t rate, int32_t B, const int32_t *t,
+                       const double *state, double *records, void *stream);
+
 const char *cmpc_last_error(cmpc_handle *h);
 const char *cmpc_version(void);
 

@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libcmpc_amd.so")
 
 #: every symbol include/cmpc.h declares
 SYMBOLS = ("cmpc_default_spec", "cmpc_create", "cmpc_destroy", "cmpc_workspace_bytes",
-           "cmpc_solve_batch", "cmpc_last_kernel_ms", "cmpc_last_error", "cmpc_version")
+           "cmpc_solve_batch", "cmpc_last_kernel_ms", "cmpc_last_error", "cmpc_version",
+           "cmpc_tables_create", "cmpc_tables_destroy", "cmpc_build_records")
 
 _lib = None
 
@@ -43,6 +44,12 @@ def load():
     lib.cmpc_last_kernel_ms.restype = ctypes.c_int
     lib.cmpc_last_error.argtypes = [vp]
     lib.cmpc_last_error.restype = ctypes.c_char_p
+    lib.cmpc_tables_create.argtypes = [ctypes.c_int, i32] + [vp] * 7 + [ctypes.POINTER(vp)]
+    lib.cmpc_tables_create.restype = ctypes.c_int
+    lib.cmpc_tables_destroy.argtypes = [vp]
+    lib.cmpc_tables_destroy.restype = ctypes.c_int
+    lib.cmpc_build_records.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+    lib.cmpc_build_records.restype = ctypes.c_int
     lib.cmpc_version.argtypes = []
     lib.cmpc_version.restype = ctypes.c_char_p
     _lib = lib

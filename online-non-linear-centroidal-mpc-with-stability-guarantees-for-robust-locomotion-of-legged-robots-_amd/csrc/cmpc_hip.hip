@@ -33,7 +33,65 @@ __global__ void __launch_bounds__(64) cmpc_solve_kernel(cmpc::KArgs ka, int *tic
   }
 }
 
+// One workgroup per record (grid-stride over the batch), one lane per pair of output words: each
+// lane assembles two consecutive doubles and issues one 16-byte store, so a wavefront writes 1 KiB of
+// contiguous record per instruction; reads are gathers from tables that stay L2-resident
+// (T x 30 doubles ~ 0.5 MB).  No integer division by the record length.  HBM-bound on the write side.
+__device__ __forceinline__ double cmpc_record_word(int e, int t, int N, int rate, const double *__restrict__ st16,
+                                                   const double *__restrict__ com_tab, const double *__restrict__ pose_l,
+                                                   const double *__restrict__ pose_r, const double *__restrict__ gl,
+                                                   const double *__restrict__ gr, const double *__restrict__ cur_l,
+                                                   const double *__restrict__ cur_r) {
+  if (e < 12) return st16[e];
+  if (e == 12) return st16[12];
+  if (e < 16) return cur_l[(size_t)t * 3 + e - 13];
+  if (e == 16) return st16[13];
+  if (e < 20) return cur_r[(size_t)t * 3 + e - 17];
+  if (e < 22) return st16[14 + e - 20];
+  if (e == 22) return gl[t + N * rate];
+  if (e == 23) return gr[t + N * rate];
+  const int i = (e - 24) / 19, c = (e - 24) - 19 * i;
+  const int tt = t + (1 + i) * rate;
+  if (c < 9) return com_tab[(size_t)tt * 9 + c];
+  if (c < 12) return pose_l[(size_t)tt * 6 + 3 + c - 9];
+  if (c < 15) return pose_r[(size_t)tt * 6 + 3 + c - 12];
+  if (c == 15) return pose_l[(size_t)tt * 6 + 2];
+  if (c == 16) return pose_r[(size_t)tt * 6 + 2];
+  if (c == 17) return gl[t + i * rate];
+  return gr[t + i * rate];
+}
+
+__global__ void __launch_bounds__(256) cmpc_build_records_kernel(
+    int T, int N, int rate, int B, int nrec, const int *__restrict__ tick, const double *__restrict__ state,
+    const double *__restrict__ com_tab, const double *__restrict__ pose_l, const double *__restrict__ pose_r,
+    const double *__restrict__ gl, const double *__restrict__ gr, const double *__restrict__ cur_l,
+    const double *__restrict__ cur_r, double *__restrict__ rec) {
+  const double nanv = __builtin_nan("");
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int t = tick[b];
+    const bool bad = t < 0 || t + (N + 1) * rate >= T;
+    const double *st16 = state + (size_t)b * 16;
+    double *out = rec + (size_t)b * nrec;
+    const bool aligned = ((nrec & 1) == 0);             // even record length: every pair is 16-byte aligned
+    for (int e = 2 * threadIdx.x; e < nrec; e += 2 * blockDim.x) {
+      const double v0 = bad ? nanv : cmpc_record_word(e, t, N, rate, st16, com_tab, pose_l, pose_r, gl, gr, cur_l, cur_r);
+      if (e + 1 < nrec) {
+        const double v1 = bad ? nanv : cmpc_record_word(e + 1, t, N, rate, st16, com_tab, pose_l, pose_r, gl, gr, cur_l, cur_r);
+        if (aligned) *reinterpret_cast<double2 *>(out + e) = make_double2(v0, v1);
+        else { out[e] = v0; out[e + 1] = v1; }
+      } else out[e] = v0;
+    }
+  }
+}
+
 }  // namespace
+
+struct cmpc_tables {
+  int device = 0;
+  int T = 0;
+  double *com_tab = nullptr, *pose_l = nullptr, *pose_r = nullptr, *gl = nullptr, *gr = nullptr,
+         *cur_l = nullptr, *cur_r = nullptr;
+};
 
 struct cmpc_handle {
   cmpc_spec spec;
@@ -171,6 +229,55 @@ int cmpc_last_kernel_ms(cmpc_handle *h, float *ms) {
   if (!h->timed) return fail(h, "cmpc_last_kernel_ms: no launch recorded");
   HIP_TRY(h, hipEventSynchronize(h->ev1));
   HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return 0;
+}
+
+int cmpc_tables_create(int device, int32_t T, const double *com_tab, const double *pose_l, const double *pose_r,
+                       const double *gl, const double *gr, const double *cur_l, const double *cur_r,
+                       cmpc_tables **out) {
+  if (!out) return fail(nullptr, "cmpc_tables_create: null out pointer");
+  *out = nullptr;
+  if (T <= 0 || !com_tab || !pose_l || !pose_r || !gl || !gr || !cur_l || !cur_r)
+    return fail(nullptr, "cmpc_tables_create: bad argument");
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "cmpc_tables_create: bad device");
+  cmpc_tables *tb = new cmpc_tables();
+  tb->device = device; tb->T = T;
+  struct { double **dst; const double *src; size_t n; } items[] = {
+      {&tb->com_tab, com_tab, (size_t)T * 9}, {&tb->pose_l, pose_l, (size_t)T * 6}, {&tb->pose_r, pose_r, (size_t)T * 6},
+      {&tb->gl, gl, (size_t)T}, {&tb->gr, gr, (size_t)T}, {&tb->cur_l, cur_l, (size_t)T * 3}, {&tb->cur_r, cur_r, (size_t)T * 3}};
+  for (auto &it : items) {
+    if (hipMalloc(it.dst, it.n * sizeof(double)) != hipSuccess ||
+        hipMemcpy(*it.dst, it.src, it.n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      cmpc_tables_destroy(tb);
+      return fail(nullptr, "cmpc_tables_create: device allocation / upload failed");
+    }
+  }
+  *out = tb;
+  return 0;
+}
+
+int cmpc_tables_destroy(cmpc_tables *tb) {
+  if (!tb) return 0;
+  (void)hipSetDevice(tb->device);
+  double *ptrs[] = {tb->com_tab, tb->pose_l, tb->pose_r, tb->gl, tb->gr, tb->cur_l, tb->cur_r};
+  for (double *p : ptrs) if (p) (void)hipFree(p);
+  delete tb;
+  return 0;
+}
+
+int cmpc_build_records(const cmpc_tables *tb, int32_t N, int32_t rate, int32_t B, const int32_t *t,
+                       const double *state, double *records, void *stream) {
+  if (!tb) return fail(nullptr, "cmpc_build_records: null tables");
+  if (N < 1 || N > CMPC_MAX_N || rate < 1 || B < 0) return fail(nullptr, "cmpc_build_records: bad argument");
+  if (B == 0) return 0;
+  if (!t || !state || !records) return fail(nullptr, "cmpc_build_records: null buffer");
+  if (hipSetDevice(tb->device) != hipSuccess) return fail(nullptr, "cmpc_build_records: bad device");
+  const int nrec = CMPC_NREC(N);
+  const int blocks = B < 256 * 32 ? B : 256 * 32;      // grid-stride beyond 32 workgroups per CU
+  hipLaunchKernelGGL(cmpc_build_records_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tb->T, N, rate,
+                     B, nrec, t, state, tb->com_tab, tb->pose_l, tb->pose_r, tb->gl, tb->gr, tb->cur_l, tb->cur_r,
+                     records);
+  if (hipGetLastError() != hipSuccess) return fail(nullptr, "cmpc_build_records: launch failed");
   return 0;
 }
 

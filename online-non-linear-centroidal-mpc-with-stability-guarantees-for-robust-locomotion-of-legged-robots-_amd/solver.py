@@ -83,3 +83,53 @@ class BatchedCentroidalMPC:
         if rc != 0:
             raise RuntimeError(self._lib.cmpc_last_error(self._h).decode())
         return ms.value
+
+
+class DeviceRecordBuilder:
+    """Device-side front half of ``centroidal_mpc.solve`` (code/centroidal_mpc_vertices.py:482-600): the
+    per-tick tables of a ``workloads.Scene`` are uploaded once, then records for a whole batch are
+    gathered on the GPU (``cmpc_build_records``) - no host loop, no host-to-device copy per tick."""
+
+    def __init__(self, scene, device=None):
+        import numpy as np
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeviceRecordBuilder needs a ROCm GPU: there is no CPU fallback")
+        self.device = (torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device))
+        self._lib = capi.load()
+        T = scene.T
+        arrs = [np.ascontiguousarray(a[:T], dtype=np.float64) for a in
+                (scene.com_tab, scene.pose_l, scene.pose_r, scene.gl_tab, scene.gr_tab, scene.cur_l, scene.cur_r)]
+        h = ctypes.c_void_p()
+        rc = self._lib.cmpc_tables_create(self.device.index or 0, T, *[a.ctypes.data_as(ctypes.c_void_p) for a in arrs],
+                                          ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError("cmpc_tables_create failed: " + self._lib.cmpc_last_error(None).decode())
+        self._h, self.T = h, T
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cmpc_tables_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build(self, spec, t, state, rate=1, out=None):
+        """t (B,) int32 and state (B, 16) fp64 on the GPU -> records (B, nrec) on the GPU."""
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+            raise ValueError("t must be a contiguous int32 CUDA tensor")
+        B = t.shape[0]
+        if not (state.is_cuda and state.dtype == torch.float64 and state.is_contiguous()
+                and tuple(state.shape) == (B, 16)):
+            raise ValueError("state must be a contiguous fp64 CUDA tensor of shape (B, 16)")
+        if out is None:
+            out = torch.empty((B, spec.nrec), dtype=torch.float64, device=t.device)
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        rc = self._lib.cmpc_build_records(self._h, spec.N, rate, B, t.data_ptr(), state.data_ptr(), out.data_ptr(),
+                                          ctypes.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("cmpc_build_records failed: " + self._lib.cmpc_last_error(None).decode())
+        return out

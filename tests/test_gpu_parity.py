@@ -157,3 +157,27 @@ def test_drop_in_class_matches_reference_call_sites(gpu, oracle, scene):
     with pytest.raises(RuntimeError):
         bad = copy.deepcopy(current); bad['com']['pos'] = np.array([0.3, 0.0, 0.95])   # above the height bound
         mpc.solve(bad, 208)
+
+
+def test_device_record_builder_is_bit_exact(gpu, scene):
+    """Gather kernel vs the host builder (itself pinned to the scalar front half of ``solve`` and to
+    the reference's fixtures): integer / copy work, so the bar is bit-exact."""
+    from cmpc_amd.solver import DeviceRecordBuilder
+    rng = np.random.default_rng(3)
+    for N in (10, 20, 40):
+        spec = ProblemSpec(N=N)
+        B = 3001
+        t = rng.integers(0, scene.t_max(N) + 1, size=B).astype(np.int32)
+        t[:3] = [0, 199, scene.t_max(N)]                     # edges of the tick range
+        state = rng.normal(size=(B, 16))
+        want = scene.build_records(spec, t, state[:, 0:3], state[:, 3:6], state[:, 6:9], state[:, 9:12], state[:, 12],
+                                   state[:, 13], state[:, 14], state[:, 15])
+        bld = DeviceRecordBuilder(scene, device="cuda:0")
+        got = bld.build(spec, torch.from_numpy(t).to("cuda:0"), torch.from_numpy(state).to("cuda:0"))
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), want)
+    # out-of-range ticks are flagged, not read out of bounds
+    bad = torch.tensor([scene.T, -1], dtype=torch.int32, device="cuda:0")
+    out = bld.build(spec, bad, torch.zeros((2, 16), dtype=torch.float64, device="cuda:0"))
+    assert torch.isnan(out).all()
+    assert bld.build(spec, bad[:0], torch.zeros((0, 16), dtype=torch.float64, device="cuda:0")).shape == (0, spec.nrec)
