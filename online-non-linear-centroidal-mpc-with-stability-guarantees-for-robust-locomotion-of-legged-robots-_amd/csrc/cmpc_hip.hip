@@ -12,10 +12,16 @@
 
 #include "cmpc_kernel.hpp"
 
+// Register budget: 2 waves per SIMD (<= 256 VGPR+AGPR) lets a CU hold 5 single-wave workgroups
+// (LDS-limited) instead of 4 (one per SIMD).
+#ifndef CMPC_WAVES_PER_SIMD
+#define CMPC_WAVES_PER_SIMD 2
+#endif
+
 namespace {
 
 template <int NV>
-__global__ void __launch_bounds__(64) cmpc_solve_kernel(cmpc::KArgs ka, int *ticket) {
+__global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_solve_kernel(cmpc::KArgs ka, int *ticket) {
   using D = cmpc::Dims<NV>;
   __shared__ double lds[D::LDS_DOUBLES];
   __shared__ int next;

@@ -105,8 +105,7 @@ template <int NV> struct Dims {
   static constexpr int TS = TH | 1;
   // ---- LDS map (doubles) ----
   static constexpr int oM = 0;
-  static constexpr int oT = oM + NTRI + (NTRI & 1);
-  static constexpr int oP = oT + NXA * TS + ((NXA * TS) & 1);
+  static constexpr int oP = oM + NTRI + (NTRI & 1);
   static constexpr int oXK = oP + NXA * PS + ((NXA * PS) & 1);
   static constexpr int oUK = oXK + NXA;
   static constexpr int oXN1 = oUK + NU;
@@ -132,8 +131,13 @@ template <int NV> struct Dims {
   static constexpr int oSR = oUPX + NU;       // stage record k (19), k-1 (19), header (24)
   static constexpr int oSRP = oSR + 20;
   static constexpr int oHDR = oSRP + 20;
-  static constexpr int oRED = oHDR + 24;      // 64 reduction slots
-  static constexpr int LDS_DOUBLES = oRED + 64;
+  static constexpr int oRED = oHDR + 24;      // 4 scratch slots
+  // The staging tile of T = P [B A] (NXA x TS) aliases the per-stage evaluation vectors
+  // [oSK, oTV + NZ) when it fits (nv = 4): all of them are dead between build_H and the next
+  // stage's load.  Otherwise (nv = 8) it gets its own region.
+  static constexpr bool T_ALIAS = (oSK + NXA * TS <= oTV + NZ);
+  static constexpr int oT = T_ALIAS ? oSK : oRED + 4;
+  static constexpr int LDS_DOUBLES = T_ALIAS ? oRED + 4 : oRED + 4 + NXA * TS;
   // ---- global scratch map per stage (doubles) ----
   static constexpr int gLAM = 0;
   static constexpr int gLS = gLAM + NU * NU;
@@ -943,6 +947,7 @@ template <int NV> struct Solver {
           st[D::gPB + lane] = a;
           st[D::gB + lane] = L(D::oBV + lane);
         }
+        CMPC_SYNC();                            // the T tile of add_GtPG aliases BV and the other stage vectors
         CMPC_TICK(13);
         CMPC_OPAQUE(lane);
 #ifndef CMPC_X_NO_GTPG
