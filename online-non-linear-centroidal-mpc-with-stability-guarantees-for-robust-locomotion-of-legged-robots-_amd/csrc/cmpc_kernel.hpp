@@ -131,7 +131,10 @@ template <int NV> struct Dims {
   static constexpr int oSR = oUPX + NU;       // stage record k (19), k-1 (19), header (24)
   static constexpr int oSRP = oSR + 20;
   static constexpr int oHDR = oSRP + 20;
-  static constexpr int oRED = oHDR + 24;      // 4 scratch slots
+  static constexpr int oH0 = oHDR + 24;       // gradient parts h = h0 + mu*h1 of the stage (NZ each)
+  static constexpr int oH1 = oH0 + NZ;
+  static constexpr int oPC1 = oH1 + NZ;       // mu-coefficient of the cost-to-go gradient (NXA)
+  static constexpr int oRED = oPC1 + NXA;     // 4 scratch slots
   // The staging tile of T = P [B A] (NXA x TS) aliases the per-stage evaluation vectors
   // [oSK, oTV + NZ) when it fits (nv = 4): all of them are dead between build_H and the next
   // stage's load.  Otherwise (nv = 8) it gets its own region.
@@ -151,7 +154,9 @@ template <int NV> struct Dims {
   static constexpr int gPV = gPB + NXA;
   static constexpr int gL = gPV + NXA;
   static constexpr int gG = gL + NU;
-  static constexpr int STAGE = ((gG + NI + 7) / 8) * 8;
+  static constexpr int gL1 = gG + NI;         // l = gL + mu*gL1,  p = gPV + mu*gPV1
+  static constexpr int gPV1 = gL1 + NU;
+  static constexpr int STAGE = ((gPV1 + NXA + 7) / 8) * 8;
   // iterate arrays follow the (N+1) stage blocks
   static size_t scratch_doubles(int N) {
     size_t n = (size_t)(N + 1) * STAGE;
@@ -849,6 +854,60 @@ template <int NV> struct Solver {
       for (int e = lane; e < NXA * NXA; e += 64) st[D::gPK + e] = L(D::oP + (e / NXA) * D::PS + (e % NXA));
   }
 
+  // Backward vector recursion of stage k, run inside the matrix sweep while L and Ls are still in
+  // LDS (packed rows of M).  The barrier value is only known after the whole sweep, but the
+  // recursion is linear in the gradient h = h0 + mu*h1, so both coefficient sets are propagated:
+  //   l = l0 + mu*l1,   p = p0 + mu*p1.
+  // Entry: XN1 = p0_{k+1} + P_{k+1} b,  PC1 = p1_{k+1},  H0/H1 = gradient parts of this stage.
+  CMPC_DEV void backward_vectors(int k) {
+    double *st = stage(k);
+    const double *M = &L(D::oM);
+    // m = h + [B A]'(.)   (scratch: TV for the mu^0 part, AL for the mu^1 part; both dead here)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int col = lane + 64 * h;
+      if (col >= NZ) continue;
+      double a0 = L(D::oH0 + col), a1 = L(D::oH1 + col);
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        a0 += lg[h][n] * L(D::oXN1 + lr[h][n]);
+        a1 += lg[h][n] * L(D::oPC1 + lr[h][n]);
+      }
+      L(D::oTV + col) = a0; L(D::oAL + col) = a1;
+    }
+    CMPC_SYNC();
+    {                                          // l = L^-1 m_u for both right-hand sides at once
+      const int li = (lane < NU) ? lane : NU - 1;
+      const double *ri = M + tri(li);
+      double m0 = L(D::oTV + li), m1 = L(D::oAL + li);
+      const double dinv = 1.0 / ri[li];
+#pragma unroll 8
+      for (int j = 0; j < NU; ++j) {
+        const double l0j = CMPC_BCAST(m0 * dinv, j), l1j = CMPC_BCAST(m1 * dinv, j);
+        const double lij = ri[(j <= li) ? j : li];     // entries right of the diagonal do not exist
+        if (lane > j) { m0 -= lij * l0j; m1 -= lij * l1j; }
+      }
+      if (lane < NU) {
+        L(D::oTV + lane) = m0 * dinv; L(D::oAL + lane) = m1 * dinv;
+        st[D::gL + lane] = m0 * dinv; st[D::gL1 + lane] = m1 * dinv;
+      }
+    }
+    CMPC_SYNC();
+    if (lane < NXA) {                          // p = m_x - Ls l
+      const double *lsr = M + tri(NU + lane), *l0 = &L(D::oTV), *l1 = &L(D::oAL);
+      double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < NU; q += 2) {
+        a0 += lsr[q] * l0[q]; a1 += lsr[q + 1] * l0[q + 1];
+        b0 += lsr[q] * l1[q]; b1 += lsr[q + 1] * l1[q + 1];
+      }
+      const double p0 = L(D::oTV + NU + lane) - (a0 + a1), p1 = L(D::oAL + NU + lane) - (b0 + b1);
+      L(D::oPC + lane) = p0; L(D::oPC1 + lane) = p1;
+      st[D::gPV + lane] = p0; st[D::gPV1 + lane] = p1;
+    }
+    CMPC_SYNC();
+  }
+
   struct Err { double e_d, e_p, e_c, e_cmu, sum_mult; int n_mult; };
 
   // ---------------------------------------------------------------------------------------
@@ -921,8 +980,8 @@ template <int NV> struct Solver {
         if (col >= NU) r -= L(D::oLAMK + col - NU);
         const bool is_var = (col < NU) ? (k < N) : (k >= 1);
         if (is_var) er.e_d = fmax(er.e_d, fabs(r));
-        st[D::gH0 + col] = ho + jw[1];
-        st[D::gH1 + col] = jw[2];
+        L(D::oH0 + col) = ho + jw[1];
+        L(D::oH1 + col) = jw[2];
         st[D::gAL + col] = L(D::oAL + col);
       }
       for (int c = lane; c < 3 * NZ; c += 64) st[D::gGH + c] = L(D::oGH + c);
@@ -944,7 +1003,7 @@ template <int NV> struct Solver {
             b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
           }
           const double a = (b0 + b1) + (b2 + b3);
-          st[D::gPB + lane] = a;
+          L(D::oXN1 + lane) = L(D::oPC + lane) + a;       // v0 = p0_{k+1} + P_{k+1} b
           st[D::gB + lane] = L(D::oBV + lane);
         }
         CMPC_SYNC();                            // the T tile of add_GtPG aliases BV and the other stage vectors
@@ -959,7 +1018,14 @@ template <int NV> struct Solver {
         if (!factor_stage(k)) return false;
 #endif
         CMPC_TICK(3);
+        backward_vectors(k);
+        CMPC_TICK(5);
       } else {
+        if (lane < NXA) {                      // terminal cost-to-go gradient p_N = h_N (x part), split in mu
+          const double p0 = L(D::oH0 + NU + lane), p1 = L(D::oH1 + NU + lane);
+          L(D::oPC + lane) = p0; L(D::oPC1 + lane) = p1;
+          st[D::gPV + lane] = p0; st[D::gPV1 + lane] = p1;
+        }
         for (int e = lane; e < NXA * NXA; e += 64) {
           const int i = e / NXA, c = e % NXA;
           const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
@@ -1008,60 +1074,6 @@ template <int NV> struct Solver {
   CMPC_DEV void vector_sweeps(double mu) {
     const double m = rec[20];
     CMPC_SYNC_GLOBAL();                       // P_k of the matrix sweep is re-read with another lane mapping
-    {
-      const double *st = stage(N);
-      if (lane < NXA) {
-        const double p = st[D::gH0 + NU + lane] + mu * st[D::gH1 + NU + lane];
-        L(D::oPC + lane) = p;
-        stage(N)[D::gPV + lane] = p;
-      }
-      CMPC_SYNC();
-    }
-    for (int k = N - 1; k >= 0; --k) {
-      CMPC_OPAQUE(lane);
-      load_factors(k);
-      double *st = stage(k);
-      build_list(&L(D::oGH), L(D::oSR + 17), L(D::oSR + 18), m);
-      if (lane < NXA) L(D::oXN1 + lane) = L(D::oPC + lane) + st[D::gPB + lane];
-      CMPC_SYNC();
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int col = lane + 64 * h;
-        if (col >= NZ) continue;
-        double a = st[D::gH0 + col] + mu * st[D::gH1 + col];
-        for (int n = 0; n < 6; ++n) a += lg[h][n] * L(D::oXN1 + lr[h][n]);
-        L(D::oTV + col) = a;
-      }
-      CMPC_SYNC();
-      // l = L^-1 m_u: column-oriented forward substitution, right-hand side in a register per lane,
-      // l_j broadcast by readlane (no LDS round trip in the 32-step dependent chain)
-      {
-        const int li = (lane < NU) ? lane : NU - 1;
-        double mreg = L(D::oTV + li);
-        const double dinv = 1.0 / L(D::oM + li * D::LS + li);
-#pragma unroll 8
-        for (int j = 0; j < NU; ++j) {
-          const double lj = CMPC_BCAST(mreg * dinv, j);
-          const double lij = L(D::oM + li * D::LS + j);
-          if (lane > j) mreg -= lij * lj;
-        }
-        if (lane < NU) { L(D::oTV + lane) = mreg * dinv; st[D::gL + lane] = mreg * dinv; }
-      }
-      CMPC_SYNC();
-      if (lane < NXA) {
-        const double *lsr = &L(D::oM + (NU + lane) * D::LS), *lv = &L(D::oTV);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-        for (int q = 0; q < NU; q += 4) {
-          a0 += lsr[q] * lv[q]; a1 += lsr[q + 1] * lv[q + 1]; a2 += lsr[q + 2] * lv[q + 2]; a3 += lsr[q + 3] * lv[q + 3];
-        }
-        const double a = L(D::oTV + NU + lane) - ((a0 + a1) + (a2 + a3));
-        L(D::oPC + lane) = a;
-        st[D::gPV + lane] = a;
-      }
-      CMPC_SYNC();
-    }
-    CMPC_TICK(5);
     // forward
     if (lane < NXA) { L(D::oXK + lane) = 0.0; gdx[lane] = 0.0; }
     CMPC_SYNC();
@@ -1071,7 +1083,7 @@ template <int NV> struct Solver {
       const double *st = stage(k);
       if (lane < NU) {
         const double *lsc = &L(D::oM + NU * D::LS + lane), *dxv = &L(D::oXK);
-        double a0 = st[D::gL + lane], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        double a0 = st[D::gL + lane] + mu * st[D::gL1 + lane], a1 = 0.0, a2 = 0.0, a3 = 0.0;
         static_assert(NXA % 4 == 0, "unroll by 4");
 #pragma unroll
         for (int i = 0; i < NXA; i += 4) {
@@ -1130,7 +1142,7 @@ template <int NV> struct Solver {
       CMPC_SYNC();
       if (lane < NXA) {
         const double *stn = stage(k + 1);
-        double a = stn[D::gPV + lane];
+        double a = stn[D::gPV + lane] + mu * stn[D::gPV1 + lane];
         {
           const double *pk = stn + D::gPK + lane, *xv = &L(D::oXN1);
           double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
