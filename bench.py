@@ -69,10 +69,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP solver has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # CMPC_BENCH_REHEARSAL=1: several ranks share the visible GPU(s) over gloo (to rehearse the N > 1
+    # code path on a one-GPU box); the real runs use one GPU per rank over RCCL.
+    rehearsal = os.environ.get("CMPC_BENCH_REHEARSAL") == "1"
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import cmpc_amd  # noqa: F401
     from cmpc_amd import workloads as wl, dist as cdist

@@ -43,8 +43,15 @@ def gather_shards(local, B, group=None):
     if local.shape[0] < longest:
         pad = torch.zeros((longest - local.shape[0], cols), dtype=local.dtype, device=local.device)
         padded = torch.cat((local, pad), dim=0)
-    full = torch.empty((world * longest, cols), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(full, padded.contiguous(), group=group)
+    padded = padded.contiguous()
+    if padded.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal path (several ranks sharing one GPU, gloo): stage through the host
+        host = torch.empty((world * longest, cols), dtype=local.dtype)
+        dist.all_gather_into_tensor(host, padded.cpu(), group=group)
+        full = host.to(local.device)
+    else:
+        full = torch.empty((world * longest, cols), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(full, padded, group=group)
     parts = []
     for r in range(world):
         lo, hi = shard_bounds(B, world, r)
