@@ -1061,10 +1061,25 @@ template <int NV> struct Solver {
   // Copy L (NU x NU) and Ls (NXA x NU) of stage k into LDS (M region, strides LS).
   CMPC_DEV void load_factors(int k) {
     const double *st = stage(k);
-    for (int e = lane; e < NU * NU; e += 64) L(D::oM + (e / NU) * D::LS + (e % NU)) = st[D::gLAM + e];
-    for (int e = lane; e < NXA * NU; e += 64) L(D::oM + (NU + e / NU) * D::LS + (e % NU)) = st[D::gLS + e];
-    for (int c = lane; c < 3 * NZ; c += 64) L(D::oGH + c) = st[D::gGH + c];
-    if (lane < 19) L(D::oSR + lane) = rec[24 + 19 * k + lane];
+    // All global loads are issued before the first LDS write: written as a plain copy loop, hipcc
+    // waits for each load before the dependent ds_write and the 33 round trips to HBM serialise
+    // (measured: 30 k cycles per stage, 12 % of an iteration).
+    constexpr int NLAM = (NU * NU + 63) / 64, NLS = (NXA * NU + 63) / 64, NGH = (3 * NZ + 63) / 64;
+    double vl[NLAM], vs[NLS], vg[NGH];
+#pragma unroll
+    for (int i = 0; i < NLAM; ++i) { const int e = lane + 64 * i; vl[i] = (e < NU * NU) ? st[D::gLAM + e] : 0.0; }
+#pragma unroll
+    for (int i = 0; i < NLS; ++i) { const int e = lane + 64 * i; vs[i] = (e < NXA * NU) ? st[D::gLS + e] : 0.0; }
+#pragma unroll
+    for (int i = 0; i < NGH; ++i) { const int e = lane + 64 * i; vg[i] = (e < 3 * NZ) ? st[D::gGH + e] : 0.0; }
+    const double srv = (lane < 19) ? rec[24 + 19 * k + lane] : 0.0;
+#pragma unroll
+    for (int i = 0; i < NLAM; ++i) { const int e = lane + 64 * i; if (e < NU * NU) L(D::oM + (e / NU) * D::LS + (e % NU)) = vl[i]; }
+#pragma unroll
+    for (int i = 0; i < NLS; ++i) { const int e = lane + 64 * i; if (e < NXA * NU) L(D::oM + (NU + e / NU) * D::LS + (e % NU)) = vs[i]; }
+#pragma unroll
+    for (int i = 0; i < NGH; ++i) { const int e = lane + 64 * i; if (e < 3 * NZ) L(D::oGH + e) = vg[i]; }
+    if (lane < 19) L(D::oSR + lane) = srv;
     CMPC_SYNC();
   }
 
