@@ -41,6 +41,10 @@ static __device__ __forceinline__ double cmpc_bcast(double v, int src) {
   return u.d;
 }
 #define CMPC_BCAST(v, src) cmpc_bcast((v), (src))
+// D(16x16) += A(16x4) B(4x16) on the matrix cores, fp64.  Lane l supplies A[l&15][l>>4] and
+// B[l>>4][l&15]; it receives D[(l>>4) + 4r][l&15] in component r (gfx950 f64 layout).
+typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
+#define CMPC_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 // butterfly exchange for wave-wide reductions
 #define CMPC_XOR(v, m) __shfl_xor((v), (m))
 // keeps the scheduler from hoisting every LDS read of an unrolled phase to its top (live ranges)
@@ -804,32 +808,50 @@ template <int NV> struct Solver {
     }
     CMPC_TICK(8);
     if (k == 0) return true;                 // x_0 is data: no cost-to-go needed
-    // P_k = M_xx - Ls Ls' : lane (ii, half) keeps row ii of Ls in registers and owns the columns of
-    // its half of [0, ii]; every (ii, c) entry is produced by exactly one lane and written to both
-    // triangles of P.
+    // P_k = M_xx - Ls Ls' on the matrix cores: the state rows are cut into 16-row blocks, tile (rb, cb)
+    // with cb <= rb accumulates over NU/4 k-steps of v_mfma_f64_16x16x4; since the product is Ls Ls',
+    // the B operand of column block cb is the A operand of row block cb (one LDS read per block and
+    // k-step).  Rows beyond NXA are fed zeros.
     {
-      const int hsel = lane >> 5;
-      for (int ii = (lane & 31); ii < NXA; ii += 32) {
-        const double *ri = M + tri(NU + ii);
-        double rrow[NU];
+      constexpr int NB = (NXA + 15) / 16;
+      const int r16 = lane & 15, kq = lane >> 4;
+      cmpc_v4d acc[NB][NB];
 #pragma unroll
-        for (int q = 0; q < NU; ++q) rrow[q] = ri[q];
-        const int mid = (ii + 1) / 2;
-        const int cb = hsel ? mid : 0, ce = hsel ? ii + 1 : mid;
-        for (int c = cb; c < ce; ++c) {
-          const double *rc = M + tri(NU + c);
-          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      for (int rb = 0; rb < NB; ++rb)
 #pragma unroll
-          for (int q = 0; q < NU; q += 4) {
-            a0 += rrow[q] * rc[q]; a1 += rrow[q + 1] * rc[q + 1];
-            a2 += rrow[q + 2] * rc[q + 2]; a3 += rrow[q + 3] * rc[q + 3];
-          }
-          const double v = ri[NU + c] - ((a0 + a1) + (a2 + a3));
-          L(D::oP + ii * D::PS + c) = v;
-          L(D::oP + c * D::PS + ii) = v;
-          CMPC_SCHED_FENCE();
-        }
+        for (int cb = 0; cb <= rb; ++cb) acc[rb][cb] = cmpc_v4d{0.0, 0.0, 0.0, 0.0};
+      const double *rowp[NB];
+      bool valid[NB];
+#pragma unroll
+      for (int rb = 0; rb < NB; ++rb) {
+        const int row = 16 * rb + r16;
+        valid[rb] = row < NXA;
+        rowp[rb] = M + tri(NU + (valid[rb] ? row : 0)) + kq;
       }
+#pragma unroll 2
+      for (int ks = 0; ks < NU / 4; ++ks) {
+        double a[NB];
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb) { const double v = rowp[rb][4 * ks]; a[rb] = valid[rb] ? v : 0.0; }
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+          for (int cb = 0; cb <= rb; ++cb) acc[rb][cb] = CMPC_MFMA_F64(a[rb], a[cb], acc[rb][cb]);
+      }
+#pragma unroll
+      for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb <= rb; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * rb + kq + 4 * r, j = 16 * cb + r16;   // D row / column of this component
+            if (i < NXA && j < NXA) {
+              const int hi = (i > j) ? i : j, lo = (i > j) ? j : i;
+              const double v = M[tri(NU + hi) + NU + lo] - acc[rb][cb][r];
+              L(D::oP + i * D::PS + j) = v;
+              if (rb != cb) L(D::oP + j * D::PS + i) = v;
+            }
+          }
     }
     CMPC_SYNC();
     CMPC_TICK(9);

@@ -38,6 +38,23 @@ static inline double emu_xor(double v, int m) {
 }
 #define CMPC_XOR(v, m) emu_xor((v), (m))
 #define CMPC_SCHED_FENCE() do { } while (0)
+// emulated v_mfma_f64_16x16x4: every lane publishes its A / B element, then gathers its 4 results
+struct cmpc_v4d { double v[4]; double &operator[](int i) { return v[i]; } const double &operator[](int i) const { return v[i]; } };
+static double emu_mfma_a[64], emu_mfma_b[64];
+static inline cmpc_v4d emu_mfma(double a, double b, cmpc_v4d c) {
+  emu_mfma_a[emu_lane_id] = a; emu_mfma_b[emu_lane_id] = b;
+  pthread_barrier_wait(&emu_barrier);
+  const int col = emu_lane_id & 15, rq = emu_lane_id >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = rq + 4 * r;
+    double acc = c[r];
+    for (int k = 0; k < 4; ++k) acc += emu_mfma_a[row + 16 * k] * emu_mfma_b[col + 16 * k];
+    c[r] = acc;
+  }
+  pthread_barrier_wait(&emu_barrier);
+  return c;
+}
+#define CMPC_MFMA_F64(a, b, c) emu_mfma((a), (b), (c))
 #define CMPC_OPAQUE(x) do { } while (0)
 
 #include "../../online-non-linear-centroidal-mpc-with-stability-guarantees-for-robust-locomotion-of-legged-robots-_amd/csrc/cmpc_kernel.hpp"
