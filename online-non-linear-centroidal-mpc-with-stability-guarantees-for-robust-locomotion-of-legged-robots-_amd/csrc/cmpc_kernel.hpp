@@ -733,12 +733,17 @@ template <int NV> struct Solver {
   // Cholesky of the input block, Ls, Schur complement.  Returns false on a non-positive pivot.
   // Left-looking in panels of 4 columns: the four dot products share the loads of the lane's own row
   // and are independent; the 4x4 panel itself is factorised in registers with readlane broadcasts.
-  CMPC_DEV bool factor_stage(int k) {
-    double *M = &L(D::oM);
-    static_assert(NU % 4 == 0, "panel width 4");
-    static_assert(NU <= 64, "panel rows must live in the first row set");
-    bool ok = true;
-    for (int J = 0; J < NU; J += 4) {
+  // One 16-column block of the right-looking blocked Cholesky: (1) the block's columns are factorised
+  // for all rows below (left-looking inside the block, 4-column panels in registers with readlane
+  // broadcasts), (2) the trailing matrix is updated on the matrix cores,
+  //     M[i][j] -= sum_{q in block} L[i][q] L[j][q]   for rows/cols beyond the block,
+  // 16x16 tiles of v_mfma_f64_16x16x4; the product is L21 L21', so the B operand of column block cb is
+  // the A operand of row block cb.  After the last block the state-state corner of M is
+  // P_k = M_xx - Ls Ls' (the Schur complement) without a separate pass.
+  template <int C0> CMPC_DEV bool chol_block(double *M, bool &ok, bool trailing) {
+    constexpr int W = (NU - C0 < 16) ? NU - C0 : 16;
+    static_assert(W % 4 == 0, "block width is a multiple of the 4-column panel");
+    for (int J = C0; J < C0 + W; J += 4) {
       const double *r0 = M + tri(J), *r1 = M + tri(J + 1), *r2 = M + tri(J + 2), *r3 = M + tri(J + 3);
       double l0v[NH], l1v[NH], l2v[NH], l3v[NH];
       double t10 = 0, t20 = 0, t21 = 0, t30 = 0, t31 = 0, t32 = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
@@ -750,7 +755,7 @@ template <int NV> struct Solver {
         const double *ri = M + tri(li);
         double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll 4
-        for (int q = 0; q < J; ++q) {
+        for (int q = C0; q < J; ++q) {                 // earlier blocks were applied by the trailing updates
           const double x = ri[q];
           d0 += x * r0[q]; d1 += x * r1[q]; d2 += x * r2[q]; d3 += x * r3[q];
         }
@@ -806,52 +811,63 @@ template <int NV> struct Solver {
       }
       CMPC_SYNC();
     }
+    if (!trailing) return true;
+    constexpr int R0 = C0 + W;                  // first trailing row / column
+    constexpr int NBR = (NZ - R0 + 15) / 16;
+    const int r16 = lane & 15, kq = lane >> 4;
+    cmpc_v4d acc[NBR][NBR];
+#pragma unroll
+    for (int rb = 0; rb < NBR; ++rb)
+#pragma unroll
+      for (int cb = 0; cb <= rb; ++cb) acc[rb][cb] = cmpc_v4d{0.0, 0.0, 0.0, 0.0};
+    const double *rowp[NBR];
+    bool valid[NBR];
+#pragma unroll
+    for (int rb = 0; rb < NBR; ++rb) {
+      const int row = R0 + 16 * rb + r16;
+      valid[rb] = row < NZ;
+      rowp[rb] = M + tri(valid[rb] ? row : R0) + C0 + kq;
+    }
+#pragma unroll
+    for (int ks = 0; ks < W / 4; ++ks) {
+      double a[NBR];
+#pragma unroll
+      for (int rb = 0; rb < NBR; ++rb) { const double v = rowp[rb][4 * ks]; a[rb] = valid[rb] ? v : 0.0; }
+#pragma unroll
+      for (int rb = 0; rb < NBR; ++rb)
+#pragma unroll
+        for (int cb = 0; cb <= rb; ++cb) acc[rb][cb] = CMPC_MFMA_F64(a[rb], a[cb], acc[rb][cb]);
+    }
+#pragma unroll
+    for (int rb = 0; rb < NBR; ++rb)
+#pragma unroll
+      for (int cb = 0; cb <= rb; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = R0 + 16 * rb + kq + 4 * r, j = R0 + 16 * cb + r16;   // D row / column of this component
+          if (i < NZ && j <= i) M[tri(i) + j] -= acc[rb][cb][r];
+        }
+    CMPC_SYNC();
+    return true;
+  }
+
+  // Cholesky of the input block, Ls and the cost-to-go P_k.  Returns false on a non-positive pivot.
+  CMPC_DEV bool factor_stage(int k) {
+    double *M = &L(D::oM);
+    static_assert(NU % 4 == 0, "panel width 4");
+    static_assert(NU <= 64, "panel rows must live in the first row set");
+    bool ok = true;
+    // the last block's trailing update only produces P_k, which stage 0 does not need (x_0 is data)
+    if (!chol_block<0>(M, ok, true)) return false;
+    if constexpr (NU > 16) { if (!chol_block<16>(M, ok, (NU > 32) || k > 0)) return false; }
+    if constexpr (NU > 32) { if (!chol_block<32>(M, ok, (NU > 48) || k > 0)) return false; }
+    if constexpr (NU > 48) { if (!chol_block<48>(M, ok, k > 0)) return false; }
     CMPC_TICK(8);
-    if (k == 0) return true;                 // x_0 is data: no cost-to-go needed
-    // P_k = M_xx - Ls Ls' on the matrix cores: the state rows are cut into 16-row blocks, tile (rb, cb)
-    // with cb <= rb accumulates over NU/4 k-steps of v_mfma_f64_16x16x4; since the product is Ls Ls',
-    // the B operand of column block cb is the A operand of row block cb (one LDS read per block and
-    // k-step).  Rows beyond NXA are fed zeros.
-    {
-      constexpr int NB = (NXA + 15) / 16;
-      const int r16 = lane & 15, kq = lane >> 4;
-      cmpc_v4d acc[NB][NB];
-#pragma unroll
-      for (int rb = 0; rb < NB; ++rb)
-#pragma unroll
-        for (int cb = 0; cb <= rb; ++cb) acc[rb][cb] = cmpc_v4d{0.0, 0.0, 0.0, 0.0};
-      const double *rowp[NB];
-      bool valid[NB];
-#pragma unroll
-      for (int rb = 0; rb < NB; ++rb) {
-        const int row = 16 * rb + r16;
-        valid[rb] = row < NXA;
-        rowp[rb] = M + tri(NU + (valid[rb] ? row : 0)) + kq;
-      }
-#pragma unroll 2
-      for (int ks = 0; ks < NU / 4; ++ks) {
-        double a[NB];
-#pragma unroll
-        for (int rb = 0; rb < NB; ++rb) { const double v = rowp[rb][4 * ks]; a[rb] = valid[rb] ? v : 0.0; }
-#pragma unroll
-        for (int rb = 0; rb < NB; ++rb)
-#pragma unroll
-          for (int cb = 0; cb <= rb; ++cb) acc[rb][cb] = CMPC_MFMA_F64(a[rb], a[cb], acc[rb][cb]);
-      }
-#pragma unroll
-      for (int rb = 0; rb < NB; ++rb)
-#pragma unroll
-        for (int cb = 0; cb <= rb; ++cb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * rb + kq + 4 * r, j = 16 * cb + r16;   // D row / column of this component
-            if (i < NXA && j < NXA) {
-              const int hi = (i > j) ? i : j, lo = (i > j) ? j : i;
-              const double v = M[tri(NU + hi) + NU + lo] - acc[rb][cb][r];
-              L(D::oP + i * D::PS + j) = v;
-              if (rb != cb) L(D::oP + j * D::PS + i) = v;
-            }
-          }
+    if (k == 0) return true;
+    for (int e = lane; e < NXA * NXA; e += 64) {
+      const int i = e / NXA, c = e % NXA;
+      const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
+      L(D::oP + i * D::PS + c) = M[tri(NU + hi) + NU + lo];
     }
     CMPC_SYNC();
     CMPC_TICK(9);

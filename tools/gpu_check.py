@@ -67,6 +67,6 @@ if os.environ.get("CMPC_PROF"):
     ps.solve(d_rec); torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 16)()
     ps._lib.cmpc_profile_read(ps._h, buf)
-    tot = float(sum(buf)); names = ["fwd_load_factors(+rest)", "fwd_tj", "-", "fwd_backsubst", "fwd_dxn", "bwd_vectors", "fwd_lambda+loop", "step", "chol", "schur", "GtPG_T", "load+geom", "ineq", "Pb", "GtPG_Mupd", "-"]
+    tot = float(sum(buf)); names = ["eval_rest", "build_H", "-", "-", "store", "bwd_vectors", "vec_fwd", "step", "chol", "schur", "GtPG_T", "load+geom", "ineq", "Pb", "GtPG_Mupd", "-"]
     print("phase cycles (sum over instances):", {n: "%.1f%%" % (100 * b / tot) for n, b in zip(names, buf)})
     print("cycles per instance-iteration: %.0f" % (tot / it.sum()))
