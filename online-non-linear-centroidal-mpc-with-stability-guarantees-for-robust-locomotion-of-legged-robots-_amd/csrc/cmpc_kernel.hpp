@@ -20,6 +20,10 @@
 #pragma once
 #include "../../include/cmpc.h"
 #include <math.h>
+#ifdef CMPC_HOST_EMU
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 #ifndef CMPC_HOST_EMU
 #include <hip/hip_runtime.h>
@@ -147,9 +151,14 @@ template <int NV> struct Dims {
   static constexpr int LDS_DOUBLES = T_ALIAS ? oRED + 4 : oRED + 4 + NXA * TS;
   // ---- global scratch map per stage (doubles) ----
   static constexpr int gLAM = 0;
+  // Ls (NXA x NU) and P_k (NXA x NXA) as the forward sweep reads them, column c of both in one
+  // 64-wide row when the stage block fits the wave:  W[c][lane] = lane < NU ? Ls[c][lane] : P[c][lane-NU]
+  static constexpr bool W_MERGE = (NZ <= 64);
+  static constexpr int LSS = W_MERGE ? 64 : NU;          // row strides
+  static constexpr int PKS = W_MERGE ? 64 : NXA;
   static constexpr int gLS = gLAM + NU * NU;
-  static constexpr int gPK = gLS + NXA * NU;
-  static constexpr int gH0 = gPK + NXA * NXA;
+  static constexpr int gPK = W_MERGE ? gLS + NU : gLS + NXA * NU;
+  static constexpr int gH0 = W_MERGE ? gLS + NXA * 64 : gPK + NXA * NXA;
   static constexpr int gH1 = gH0 + NZ;
   static constexpr int gAL = gH1 + NZ;
   static constexpr int gGH = gAL + NZ;
@@ -190,7 +199,7 @@ template <int NV> struct Solver {
   // per-lane column list of [B A]: rows / coefficients (id, h0, h1, h2, sp1, sp2)
   int lr[NH][6];
   double lg[NH][6];
-  long long tprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  long long tprof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
   bool dbg_on = false;
 
   CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
@@ -228,29 +237,41 @@ template <int NV> struct Solver {
   // ---------------------------------------------------------------------------------------
   // Stage loads: x_k, u_k, x_{k+1}, lam_k, lam_{k+1}, s_k, z_k, uprox_k and the record rows.
   // ---------------------------------------------------------------------------------------
+  // Stage iterates and record rows to LDS.  Every global load is issued unconditionally (clamped
+  // indices) before the first LDS write: loads inside lane- or stage-conditional blocks compile to
+  // one exposed HBM round trip each (load, s_waitcnt vmcnt(0), ds_write), a dozen per stage.
   CMPC_DEV void load_stage(int k, bool with_mult) {
-    for (int i = lane; i < NXA; i += 64) {
-      L(D::oXK + i) = gx[(size_t)k * NXA + i];
-      L(D::oXN1 + i) = (k < N) ? gx[(size_t)(k + 1) * NXA + i] : 0.0;
-      if (with_mult) {
-        L(D::oLAMK + i) = glam[(size_t)k * NXA + i];
-        L(D::oLAMN + i) = (k < N) ? glam[(size_t)(k + 1) * NXA + i] : 0.0;
+    static_assert(NXA <= 64 && NU <= 64, "one lane per state / input component");
+    constexpr int NIH = (NI + 63) / 64;
+    const bool in = k < N;
+    const int kn = in ? k + 1 : k, ku = in ? k : N - 1, kp = (k >= 1) ? k - 1 : 0;
+    const int ix = (lane < NXA) ? lane : 0, iu = (lane < NU) ? lane : 0, ir = (lane < 19) ? lane : 0;
+    const double x0 = gx[(size_t)k * NXA + ix], x1 = gx[(size_t)kn * NXA + ix];
+    const double u0 = gu[(size_t)ku * NU + iu], up = gupx[(size_t)ku * NU + iu];
+    const double r0 = rec[24 + 19 * ku + ir], r1 = rec[24 + 19 * kp + ir], hd = rec[(lane < 24) ? lane : 0];
+    double l0 = 0.0, l1 = 0.0, sv[NIH], zv[NIH];
+    if (with_mult) {                           // wave-uniform
+      l0 = glam[(size_t)k * NXA + ix]; l1 = glam[(size_t)kn * NXA + ix];
+#pragma unroll
+      for (int h = 0; h < NIH; ++h) {
+        const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
+        sv[h] = gsl[(size_t)k * NI + rc]; zv[h] = gz[(size_t)k * NI + rc];
       }
     }
-    for (int i = lane; i < NU; i += 64) {
-      L(D::oUK + i) = (k < N) ? gu[(size_t)k * NU + i] : 0.0;
-      L(D::oUPX + i) = (k < N) ? gupx[(size_t)k * NU + i] : 0.0;
+    if (lane < NXA) {
+      L(D::oXK + lane) = x0; L(D::oXN1 + lane) = in ? x1 : 0.0;
+      if (with_mult) { L(D::oLAMK + lane) = l0; L(D::oLAMN + lane) = in ? l1 : 0.0; }
     }
-    if (with_mult)
-      for (int i = lane; i < NI; i += 64) {
-        L(D::oSK + i) = gsl[(size_t)k * NI + i];
-        L(D::oZK + i) = gz[(size_t)k * NI + i];
+    if (lane < NU) { L(D::oUK + lane) = in ? u0 : 0.0; L(D::oUPX + lane) = in ? up : 0.0; }
+    if (with_mult) {
+#pragma unroll
+      for (int h = 0; h < NIH; ++h) {
+        const int r = lane + 64 * h;
+        if (r < NI) { L(D::oSK + r) = sv[h]; L(D::oZK + r) = zv[h]; }
       }
-    if (lane < 19) {
-      L(D::oSR + lane) = (k < N) ? rec[24 + 19 * k + lane] : 0.0;
-      L(D::oSRP + lane) = (k >= 1) ? rec[24 + 19 * (k - 1) + lane] : 0.0;
     }
-    if (lane >= 32 && lane < 56) L(D::oHDR + lane - 32) = rec[lane - 32];
+    if (lane < 19) { L(D::oSR + lane) = in ? r0 : 0.0; L(D::oSRP + lane) = (k >= 1) ? r1 : 0.0; }
+    if (lane < 24) L(D::oHDR + lane) = hd;
     CMPC_SYNC();
   }
 
@@ -883,12 +904,20 @@ template <int NV> struct Solver {
         const int i = e / NU, j = e % NU;
         st[D::gLAM + e] = (j <= i) ? M[tri(i) + j] : 0.0;
       }
-      for (int e = lane; e < NXA * NU; e += 64) {
-        const int i = e / NU, j = e % NU;
-        st[D::gLS + e] = M[tri(NU + i) + j];
-      }
+      if constexpr (!D::W_MERGE)
+        for (int e = lane; e < NXA * NU; e += 64) {
+          const int i = e / NU, j = e % NU;
+          st[D::gLS + e] = M[tri(NU + i) + j];
+        }
     }
-    if (k >= 1)
+    if constexpr (D::W_MERGE) {
+      const bool a = lane < NU && k < N, b = lane >= NU && lane < NZ && k >= 1;
+      if (a || b) {
+#pragma unroll 4
+        for (int c = 0; c < NXA; ++c)
+          st[D::gLS + c * 64 + lane] = a ? M[tri(NU + c) + lane] : L(D::oP + c * D::PS + lane - NU);
+      }
+    } else if (k >= 1)
       for (int e = lane; e < NXA * NXA; e += 64) st[D::gPK + e] = L(D::oP + (e / NXA) * D::PS + (e % NXA));
   }
 
@@ -1097,74 +1126,94 @@ template <int NV> struct Solver {
   }
 
   // Copy L (NU x NU) and Ls (NXA x NU) of stage k into LDS (M region, strides LS).
-  CMPC_DEV void load_factors(int k) {
-    const double *st = stage(k);
-    // All global loads are issued before the first LDS write: written as a plain copy loop, hipcc
-    // waits for each load before the dependent ds_write and the 33 round trips to HBM serialise
-    // (measured: 30 k cycles per stage, 12 % of an iteration).
-    constexpr int NLAM = (NU * NU + 63) / 64, NLS = (NXA * NU + 63) / 64, NGH = (3 * NZ + 63) / 64;
-    double vl[NLAM], vs[NLS], vg[NGH];
-#pragma unroll
-    for (int i = 0; i < NLAM; ++i) { const int e = lane + 64 * i; vl[i] = (e < NU * NU) ? st[D::gLAM + e] : 0.0; }
-#pragma unroll
-    for (int i = 0; i < NLS; ++i) { const int e = lane + 64 * i; vs[i] = (e < NXA * NU) ? st[D::gLS + e] : 0.0; }
-#pragma unroll
-    for (int i = 0; i < NGH; ++i) { const int e = lane + 64 * i; vg[i] = (e < 3 * NZ) ? st[D::gGH + e] : 0.0; }
-    const double srv = (lane < 19) ? rec[24 + 19 * k + lane] : 0.0;
-#pragma unroll
-    for (int i = 0; i < NLAM; ++i) { const int e = lane + 64 * i; if (e < NU * NU) L(D::oM + (e / NU) * D::LS + (e % NU)) = vl[i]; }
-#pragma unroll
-    for (int i = 0; i < NLS; ++i) { const int e = lane + 64 * i; if (e < NXA * NU) L(D::oM + (NU + e / NU) * D::LS + (e % NU)) = vs[i]; }
-#pragma unroll
-    for (int i = 0; i < NGH; ++i) { const int e = lane + 64 * i; if (e < 3 * NZ) L(D::oGH + e) = vg[i]; }
-    if (lane < 19) L(D::oSR + lane) = srv;
-    CMPC_SYNC();
-  }
-
   // ---------------------------------------------------------------------------------------
-  // Vector sweeps: l_k, p_k backwards, then du, dx, lam+ forwards.
+  // Forward sweep: du_k, dx_{k+1}, lam_k.  The factors are read from the slab straight into
+  // registers, one batch of independent loads per stage (one HBM round trip): lane j < NU holds
+  // column j of Ls and of Lambda, and lane NU + r (or lane r when the stage block is wider than the
+  // wave) holds column r of P_k, so  Ls' dx  and  P dx  are the same instruction stream.
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void vector_sweeps(double mu) {
     const double m = rec[20];
-    CMPC_SYNC_GLOBAL();                       // P_k of the matrix sweep is re-read with another lane mapping
-    // forward
+    constexpr bool MERGE = (NZ <= 64);
+    constexpr int NGH = (3 * NZ + 63) / 64;
+    const bool isA = lane < NU;
+    const int lb = MERGE ? lane - NU : lane;
+    const bool isB = lb >= 0 && lb < NXA;
+    CMPC_SYNC_GLOBAL();                       // the slab was written with another lane mapping
     if (lane < NXA) { L(D::oXK + lane) = 0.0; gdx[lane] = 0.0; }
     CMPC_SYNC();
-    for (int k = 0; k < N; ++k) {
+    for (int k = 0; k <= N; ++k) {
       CMPC_OPAQUE(lane);
-      load_factors(k);
       const double *st = stage(k);
-      if (lane < NU) {
-        const double *lsc = &L(D::oM + NU * D::LS + lane), *dxv = &L(D::oXK);
-        double a0 = st[D::gL + lane] + mu * st[D::gL1 + lane], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      const bool hasA = k < N, hasB = k >= 1;
+      // ---- every global load of the stage, before any use
+      double vg[NGH];
+#pragma unroll
+      for (int i = 0; i < NGH; ++i) { const int e = lane + 64 * i; vg[i] = st[D::gGH + ((e < 3 * NZ) ? e : 0)]; }
+      const double srv = rec[24 + 19 * ((k < N) ? k : N - 1) + ((lane < 19) ? lane : 0)];
+      double wa[NXA], wb[MERGE ? 1 : NXA], lam[NU];
+      {
+        const double *pa = st + D::gLS + ((MERGE || isA) ? lane : 0);
+#pragma unroll
+        for (int c = 0; c < NXA; ++c) wa[c] = pa[c * D::LSS];
+        if constexpr (!MERGE) {
+          const double *pb = st + D::gPK + (isB ? lb : 0);
+#pragma unroll
+          for (int c = 0; c < NXA; ++c) wb[c] = pb[c * NXA];
+        } else wb[0] = 0.0;
+      }
+      const int la = isA ? lane : 0;
+      const double l0v = st[D::gL + la], l1v = st[D::gL1 + la], dg = st[D::gLAM + la * NU + la];
+      const int lbc = isB ? lb : 0;
+      const double pv0 = st[D::gPV + lbc], pv1 = st[D::gPV1 + lbc];
+      const double bq = st[D::gB + ((lane < NXA) ? lane : 0)];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) lam[j] = st[D::gLAM + j * NU + la];
+      // ---- stage rows of the dynamics Jacobian and the record go to LDS for dx+
+#pragma unroll
+      for (int i = 0; i < NGH; ++i) { const int e = lane + 64 * i; if (e < 3 * NZ) L(D::oGH + e) = vg[i]; }
+      if (lane < 19) L(D::oSR + lane) = srv;
+      CMPC_TICK(16);
+      // ---- Ls' dx (lanes < NU) and P dx (the other role)
+      double accA, accB;
+      {
+        const double *dxv = &L(D::oXK);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         static_assert(NXA % 4 == 0, "unroll by 4");
 #pragma unroll
-        for (int i = 0; i < NXA; i += 4) {
-          a0 += lsc[i * D::LS] * dxv[i]; a1 += lsc[(i + 1) * D::LS] * dxv[i + 1];
-          a2 += lsc[(i + 2) * D::LS] * dxv[i + 2]; a3 += lsc[(i + 3) * D::LS] * dxv[i + 3];
+        for (int c = 0; c < NXA; c += 4) {
+          a0 += wa[c] * dxv[c]; a1 += wa[c + 1] * dxv[c + 1]; a2 += wa[c + 2] * dxv[c + 2]; a3 += wa[c + 3] * dxv[c + 3];
         }
-        L(D::oTV + lane) = -((a0 + a1) + (a2 + a3));
+        accA = (a0 + a1) + (a2 + a3);
+        if constexpr (!MERGE) {
+          double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+#pragma unroll
+          for (int c = 0; c < NXA; c += 4) {
+            b0 += wb[c] * dxv[c]; b1 += wb[c + 1] * dxv[c + 1]; b2 += wb[c + 2] * dxv[c + 2]; b3 += wb[c + 3] * dxv[c + 3];
+          }
+          accB = (b0 + b1) + (b2 + b3);
+        } else accB = accA;
       }
-      CMPC_SYNC();
-      {                                        // L' du = t, same scheme backwards
-        const int li = (lane < NU) ? lane : NU - 1;
-        double treg = L(D::oTV + li);
-        const double dinv = 1.0 / L(D::oM + li * D::LS + li);
-#pragma unroll 8
+      if (hasB && isB) glamn[(size_t)k * NXA + lb] = pv0 + mu * pv1 + accB;
+      if (!hasA) { CMPC_SYNC(); break; }      // the caller reuses XK
+      {                                        // L' du = -(l + Ls' dx), multipliers by readlane
+        double treg = isA ? -(l0v + mu * l1v + accA) : 0.0;
+        const double dinv = 1.0 / dg;
+#pragma unroll
         for (int j = NU - 1; j >= 0; --j) {
           const double dj = CMPC_BCAST(treg * dinv, j);
-          const double lji = L(D::oM + j * D::LS + li);
-          if (lane < j) treg -= lji * dj;
+          if (lane < j) treg -= lam[j] * dj;
         }
-        if (lane < NU) { gdu[(size_t)k * NU + lane] = treg * dinv; L(D::oUK + lane) = treg * dinv; }
+        if (isA) { gdu[(size_t)k * NU + lane] = treg * dinv; L(D::oUK + lane) = treg * dinv; }
       }
       CMPC_SYNC();
+      CMPC_TICK(17);
       // dx+ = b + [B A] (du, dx)
       if (lane < NXA) {
         const int q = lane;
         const double d = sp.delta, gl = L(D::oSR + 17), gr = L(D::oSR + 18);
         const double *dx = &L(D::oXK), *du = &L(D::oUK);
-        double a = st[D::gB + q];
+        double a = bq;
         if (q < 3) a += dx[q] + d * dx[3 + q];
         else if (q < 6) {
           double fs = 0.0;
@@ -1190,28 +1239,13 @@ template <int NV> struct Solver {
         else if (q == 16) a += dx[16] + d * (1 - gr) * du[6 * NV + 7];
         else if (q < 20) a += dx[q] + d * (1 - gr) * du[6 * NV + 3 + q - 17];
         else a += du[3 * (q - 20) + 2];
+        gdx[(size_t)(k + 1) * NXA + q] = a;
         L(D::oXN1 + q) = a;
       }
-      CMPC_SYNC();
-      if (lane < NXA) {
-        const double *stn = stage(k + 1);
-        double a = stn[D::gPV + lane] + mu * stn[D::gPV1 + lane];
-        {
-          const double *pk = stn + D::gPK + lane, *xv = &L(D::oXN1);
-          double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-#pragma unroll
-          for (int j = 0; j < NXA; j += 4) {
-            b0 += pk[j * NXA] * xv[j]; b1 += pk[(j + 1) * NXA] * xv[j + 1];
-            b2 += pk[(j + 2) * NXA] * xv[j + 2]; b3 += pk[(j + 3) * NXA] * xv[j + 3];
-          }
-          a += (b0 + b1) + (b2 + b3);
-        }
-        glamn[(size_t)(k + 1) * NXA + lane] = a;
-        gdx[(size_t)(k + 1) * NXA + lane] = L(D::oXN1 + lane);
-      }
-      CMPC_SYNC();
+      CMPC_SYNC();                             // every lane has read dx_k
       if (lane < NXA) L(D::oXK + lane) = L(D::oXN1 + lane);
       CMPC_SYNC();
+      CMPC_TICK(18);
     }
   }
 
@@ -1238,28 +1272,50 @@ template <int NV> struct Solver {
 
   // Slack / multiplier directions and the fraction-to-the-boundary step lengths.
   CMPC_DEV void step_lengths(double mu, double &ap, double &ad) {
+    constexpr int NIH = (NI + 63) / 64;
     const double tau = fmax(0.99, 1 - mu);
     double lap = 1.0, lad = 1.0;
+    const int ix = (lane < NXA) ? lane : 0, iu = (lane < NU) ? lane : 0, ir = (lane < 19) ? lane : 0;
     for (int k = 0; k <= N; ++k) {
       CMPC_OPAQUE(lane);
       const double *st = stage(k);
-      for (int i = lane; i < NXA; i += 64) { L(D::oXK + i) = gx[(size_t)k * NXA + i]; L(D::oXN1 + i) = gdx[(size_t)k * NXA + i]; }
-      for (int i = lane; i < NU; i += 64) L(D::oUK + i) = (k < N) ? gdu[(size_t)k * NU + i] : 0.0;
-      if (lane < 19) L(D::oSR + lane) = (k < N) ? rec[24 + 19 * k + lane] : 0.0;
+      const int ku = (k < N) ? k : N - 1;
+      // one batch of loads per stage (see load_stage)
+      const double x0 = gx[(size_t)k * NXA + ix], dx0 = gdx[(size_t)k * NXA + ix];
+      const double du0 = gdu[(size_t)ku * NU + iu], r0 = rec[24 + 19 * ku + ir];
+      double al[NH], sv[NIH], zv[NIH], gv[NIH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) { const int c = lane + 64 * h; al[h] = st[D::gAL + ((c < NZ) ? c : 0)]; }
+#pragma unroll
+      for (int h = 0; h < NIH; ++h) {
+        const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
+        sv[h] = gsl[(size_t)k * NI + rc]; zv[h] = gz[(size_t)k * NI + rc]; gv[h] = st[D::gG + rc];
+      }
+      if (lane < NXA) { L(D::oXK + lane) = x0; L(D::oXN1 + lane) = dx0; }
+      if (lane < NU) L(D::oUK + lane) = (k < N) ? du0 : 0.0;
+      if (lane < 19) L(D::oSR + lane) = (k < N) ? r0 : 0.0;
       CMPC_SYNC();
       double part = 0.0;
-      for (int c = lane; c < NZ; c += 64) part += st[D::gAL + c] * ((c < NU) ? L(D::oUK + c) : L(D::oXN1 + c - NU));
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int c = lane + 64 * h;
+        if (c < NZ) part += al[h] * ((c < NU) ? L(D::oUK + c) : L(D::oXN1 + c - NU));
+      }
       const double ldot = red_sum(part);
-      for (int r = lane; r < NI; r += 64) {
-        const double s = gsl[(size_t)k * NI + r], z = gz[(size_t)k * NI + r], g = st[D::gG + r];
-        double ds = 0.0, dz = 0.0;
-        if (z != 0.0) {                       // active rows carry z > 0
-          ds = -(g + s) - jg_dot(k, r, ldot);
-          dz = (mu - s * z - z * ds) / s;
-          if (ds < 0) lap = fmin(lap, -tau * s / ds);
-          if (dz < 0) lad = fmin(lad, -tau * z / dz);
+#pragma unroll
+      for (int h = 0; h < NIH; ++h) {
+        const int r = lane + 64 * h;
+        if (r < NI) {
+          const double s = sv[h], z = zv[h], g = gv[h];
+          double ds = 0.0, dz = 0.0;
+          if (z != 0.0) {                       // active rows carry z > 0
+            ds = -(g + s) - jg_dot(k, r, ldot);
+            dz = (mu - s * z - z * ds) / s;
+            if (ds < 0) lap = fmin(lap, -tau * s / ds);
+            if (dz < 0) lad = fmin(lad, -tau * z / dz);
+          }
+          gds[(size_t)k * NI + r] = ds; gdz[(size_t)k * NI + r] = dz;
         }
-        gds[(size_t)k * NI + r] = ds; gdz[(size_t)k * NI + r] = dz;
       }
       CMPC_SYNC();
     }
@@ -1268,20 +1324,50 @@ template <int NV> struct Solver {
 
   CMPC_DEV void apply_step(double mu, double ap, double ad) {
     CMPC_SYNC_GLOBAL();                       // directions were written with a per-stage lane mapping
-    for (int e = lane; e < (N + 1) * NXA; e += 64) {
-      if (e >= NXA) {
-        gx[e] += ap * gdx[e];
-        glam[e] += ap * (glamn[e] - glam[e]);
+    // elementwise updates, four independent load groups in flight per pass
+    constexpr int UF = 4;
+    for (int e0 = NXA; e0 < (N + 1) * NXA; e0 += 64 * UF) {
+      double a[UF], b[UF], c[UF], d[UF];
+#pragma unroll
+      for (int q = 0; q < UF; ++q) {
+        const int e = e0 + lane + 64 * q, ec = (e < (N + 1) * NXA) ? e : NXA;
+        a[q] = gx[ec]; b[q] = gdx[ec]; c[q] = glam[ec]; d[q] = glamn[ec];
+      }
+#pragma unroll
+      for (int q = 0; q < UF; ++q) {
+        const int e = e0 + lane + 64 * q;
+        if (e < (N + 1) * NXA) { gx[e] = a[q] + ap * b[q]; glam[e] = c[q] + ap * (d[q] - c[q]); }
       }
     }
-    for (int e = lane; e < N * NU; e += 64) gu[e] += ap * gdu[e];
-    for (int e = lane; e < (N + 1) * NI; e += 64) {
-      double z = gz[e];
-      if (z != 0.0) {
-        const double s = gsl[e] + ap * gds[e];
-        z += ad * gdz[e];
-        const double lo = mu / s / 1e10, hi = mu / s * 1e10;
-        gsl[e] = s; gz[e] = fmin(fmax(z, lo), hi);
+    for (int e0 = 0; e0 < N * NU; e0 += 64 * UF) {
+      double a[UF], b[UF];
+#pragma unroll
+      for (int q = 0; q < UF; ++q) {
+        const int e = e0 + lane + 64 * q, ec = (e < N * NU) ? e : 0;
+        a[q] = gu[ec]; b[q] = gdu[ec];
+      }
+#pragma unroll
+      for (int q = 0; q < UF; ++q) {
+        const int e = e0 + lane + 64 * q;
+        if (e < N * NU) gu[e] = a[q] + ap * b[q];
+      }
+    }
+    for (int e0 = 0; e0 < (N + 1) * NI; e0 += 64 * UF) {
+      double zq[UF], sq[UF], dsq[UF], dzq[UF];
+#pragma unroll
+      for (int q = 0; q < UF; ++q) {
+        const int e = e0 + lane + 64 * q, ec = (e < (N + 1) * NI) ? e : 0;
+        zq[q] = gz[ec]; sq[q] = gsl[ec]; dsq[q] = gds[ec]; dzq[q] = gdz[ec];
+      }
+#pragma unroll
+      for (int q = 0; q < UF; ++q) {
+        const int e = e0 + lane + 64 * q;
+        if (e < (N + 1) * NI && zq[q] != 0.0) {
+          const double s = sq[q] + ap * dsq[q];
+          const double z = zq[q] + ad * dzq[q];
+          const double lo = mu / s / 1e10, hi = mu / s * 1e10;
+          gsl[e] = s; gz[e] = fmin(fmax(z, lo), hi);
+        }
       }
     }
     CMPC_SYNC_GLOBAL();
@@ -1370,6 +1456,7 @@ template <int NV> struct Solver {
 #else
       ap = ad = 1.0;
 #endif
+      CMPC_TICK(20);
       n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
       dbg_ap = ap; dbg_ad = ad; dbg_mu = mu;
       if (sp.reserved > 0 && it == sp.reserved - 1) break;   // diagnostic: stop before applying step
@@ -1388,7 +1475,7 @@ template <int NV> struct Solver {
       d += 2 * (N + 1) * NI;
       if (lane == 0) { d[0] = mu; d[1] = reg_last; d[2] = dbg_ap; d[3] = dbg_ad; d[4] = dbg_nreg; }
       for (int kk = 15; kk <= 18; ++kk)
-        for (int e = lane; e < NXA * NXA; e += 64) ka.dbg[50000 + (kk - 15) * 1000 + e] = stage(kk)[D::gPK + e];
+        for (int e = lane; e < NXA * NXA; e += 64) ka.dbg[50000 + (kk - 15) * 1000 + e] = stage(kk)[D::gPK + (e / NXA) * D::PKS + (e % NXA)];
       d += 8;
       // per-stage vectors of the last Newton step: h (NZ), b (NXA), l (NU), p (NXA), du (NU), dx (NXA)
       for (int k = 0; k <= N; ++k) {
@@ -1402,7 +1489,7 @@ template <int NV> struct Solver {
     }
 #if defined(CMPC_PROFILE) && !defined(CMPC_HOST_EMU)
     if (lane == 0 && ka.prof)
-      for (int i = 0; i < 16; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);
+      for (int i = 0; i < 24; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);
 #endif
     CMPC_SYNC();
   }
