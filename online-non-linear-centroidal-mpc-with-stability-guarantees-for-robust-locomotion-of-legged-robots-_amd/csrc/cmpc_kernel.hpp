@@ -162,7 +162,8 @@ template <int NV> struct Dims {
   static constexpr int gH1 = gH0 + NZ;
   static constexpr int gAL = gH1 + NZ;
   static constexpr int gGH = gAL + NZ;
-  static constexpr int gB = gGH + 3 * NZ;
+  static constexpr int GHS = 64 * NH;      // row stride of the three dense dynamics rows in the slab
+  static constexpr int gB = gGH + 3 * GHS;
   static constexpr int gPB = gB + NXA;
   static constexpr int gPV = gPB + NXA;
   static constexpr int gL = gPV + NXA;
@@ -1051,7 +1052,11 @@ template <int NV> struct Solver {
         L(D::oH1 + col) = jw[2];
         st[D::gAL + col] = L(D::oAL + col);
       }
-      for (int c = lane; c < 3 * NZ; c += 64) st[D::gGH + c] = L(D::oGH + c);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int c = lane + 64 * h;
+        if (c < NZ) { st[D::gGH + c] = L(D::oGH + c); st[D::gGH + D::GHS + c] = L(D::oGH + NZ + c); st[D::gGH + 2 * D::GHS + c] = L(D::oGH + 2 * NZ + c); }
+      }
       for (int r = lane; r < NI; r += 64) st[D::gG + r] = L(D::oGK + r);
       CMPC_TICK(0);
       CMPC_OPAQUE(lane);
@@ -1125,32 +1130,34 @@ template <int NV> struct Solver {
     return v;
   }
 
-  // Copy L (NU x NU) and Ls (NXA x NU) of stage k into LDS (M region, strides LS).
   // ---------------------------------------------------------------------------------------
   // Forward sweep: du_k, dx_{k+1}, lam_k.  The factors are read from the slab straight into
   // registers, one batch of independent loads per stage (one HBM round trip): lane j < NU holds
   // column j of Ls and of Lambda, and lane NU + r (or lane r when the stage block is wider than the
-  // wave) holds column r of P_k, so  Ls' dx  and  P dx  are the same instruction stream.
+  // wave) holds column r of P_k, so  Ls' dx  and  P dx  are the same instruction stream.  The three
+  // dense rows of [B A] (angular momentum) are held one column per lane and reduced by butterflies.
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void vector_sweeps(double mu) {
     const double m = rec[20];
-    constexpr bool MERGE = (NZ <= 64);
-    constexpr int NGH = (3 * NZ + 63) / 64;
+    constexpr bool MERGE = D::W_MERGE;
     const bool isA = lane < NU;
     const int lb = MERGE ? lane - NU : lane;
     const bool isB = lb >= 0 && lb < NXA;
     CMPC_SYNC_GLOBAL();                       // the slab was written with another lane mapping
-    if (lane < NXA) { L(D::oXK + lane) = 0.0; gdx[lane] = 0.0; }
+    int cur = D::oXK, nxt = D::oXN1;          // dx_k / dx_{k+1} ping-pong
+    if (lane < NXA) { L(cur + lane) = 0.0; gdx[lane] = 0.0; }
     CMPC_SYNC();
     for (int k = 0; k <= N; ++k) {
       CMPC_OPAQUE(lane);
       const double *st = stage(k);
       const bool hasA = k < N, hasB = k >= 1;
       // ---- every global load of the stage, before any use
-      double vg[NGH];
+      double gh[3][NH];
 #pragma unroll
-      for (int i = 0; i < NGH; ++i) { const int e = lane + 64 * i; vg[i] = st[D::gGH + ((e < 3 * NZ) ? e : 0)]; }
-      const double srv = rec[24 + 19 * ((k < N) ? k : N - 1) + ((lane < 19) ? lane : 0)];
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) gh[r][h] = st[D::gGH + r * D::GHS + lane + 64 * h];
+      const double gl = rec[24 + 19 * ((k < N) ? k : N - 1) + 17], gr = rec[24 + 19 * ((k < N) ? k : N - 1) + 18];
       double wa[NXA], wb[MERGE ? 1 : NXA], lam[NU];
       {
         const double *pa = st + D::gLS + ((MERGE || isA) ? lane : 0);
@@ -1169,15 +1176,11 @@ template <int NV> struct Solver {
       const double bq = st[D::gB + ((lane < NXA) ? lane : 0)];
 #pragma unroll
       for (int j = 0; j < NU; ++j) lam[j] = st[D::gLAM + j * NU + la];
-      // ---- stage rows of the dynamics Jacobian and the record go to LDS for dx+
-#pragma unroll
-      for (int i = 0; i < NGH; ++i) { const int e = lane + 64 * i; if (e < 3 * NZ) L(D::oGH + e) = vg[i]; }
-      if (lane < 19) L(D::oSR + lane) = srv;
       CMPC_TICK(16);
       // ---- Ls' dx (lanes < NU) and P dx (the other role)
       double accA, accB;
       {
-        const double *dxv = &L(D::oXK);
+        const double *dxv = &L(cur);
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         static_assert(NXA % 4 == 0, "unroll by 4");
 #pragma unroll
@@ -1195,7 +1198,8 @@ template <int NV> struct Solver {
         } else accB = accA;
       }
       if (hasB && isB) glamn[(size_t)k * NXA + lb] = pv0 + mu * pv1 + accB;
-      if (!hasA) { CMPC_SYNC(); break; }      // the caller reuses XK
+      if (!hasA) { CMPC_SYNC(); break; }      // the caller reuses the stage vectors
+      double duv;
       {                                        // L' du = -(l + Ls' dx), multipliers by readlane
         double treg = isA ? -(l0v + mu * l1v + accA) : 0.0;
         const double dinv = 1.0 / dg;
@@ -1204,47 +1208,44 @@ template <int NV> struct Solver {
           const double dj = CMPC_BCAST(treg * dinv, j);
           if (lane < j) treg -= lam[j] * dj;
         }
-        if (isA) { gdu[(size_t)k * NU + lane] = treg * dinv; L(D::oUK + lane) = treg * dinv; }
+        duv = treg * dinv;
+        if (isA) { gdu[(size_t)k * NU + lane] = duv; L(D::oUK + lane) = duv; }
       }
+      // dense rows: s_r = sum_c GH[r][c] z_c, z = (du, dx), one column per lane
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int c = lane + 64 * h;
+        const bool in = c < NZ;                // the row padding in the slab is never written
+        const double z = (c < NU) ? duv : (in ? L(cur + c - NU) : 0.0);
+        s0 += in ? gh[0][h] * z : 0.0; s1 += in ? gh[1][h] * z : 0.0; s2 += in ? gh[2][h] * z : 0.0;
+      }
+      s0 = red_sum(s0); s1 = red_sum(s1); s2 = red_sum(s2);
       CMPC_SYNC();
       CMPC_TICK(17);
       // dx+ = b + [B A] (du, dx)
       if (lane < NXA) {
         const int q = lane;
-        const double d = sp.delta, gl = L(D::oSR + 17), gr = L(D::oSR + 18);
-        const double *dx = &L(D::oXK), *du = &L(D::oUK);
+        const double d = sp.delta;
+        const double *dx = &L(cur), *du = &L(D::oUK);
         double a = bq;
         if (q < 3) a += dx[q] + d * dx[3 + q];
         else if (q < 6) {
           double fs = 0.0;
           for (int v = 0; v < NF; ++v) fs += ((v < NV) ? gl : gr) * du[3 * v + q - 3];
           a += dx[q] + d / m * fs;
-        } else if (q < 9) {
-          a += dx[q];
-          const double *gh = &L(D::oGH + (q - 6) * NZ);
-          double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-#pragma unroll
-          for (int c = 0; c < NU; c += 4) {
-            b0 += gh[c] * du[c]; b1 += gh[c + 1] * du[c + 1]; b2 += gh[c + 2] * du[c + 2]; b3 += gh[c + 3] * du[c + 3];
-          }
-#pragma unroll
-          for (int c = 0; c < NXA; c += 4) {
-            b0 += gh[NU + c] * dx[c]; b1 += gh[NU + c + 1] * dx[c + 1];
-            b2 += gh[NU + c + 2] * dx[c + 2]; b3 += gh[NU + c + 3] * dx[c + 3];
-          }
-          a += (b0 + b1) + (b2 + b3);
-        } else if (q < 12) a += dx[q] + d / m * (sp.k1 * dx[q - 9] + dx[q - 6]);
+        } else if (q < 9) a += dx[q] + ((q == 6) ? s0 : (q == 7) ? s1 : s2);
+        else if (q < 12) a += dx[q] + d / m * (sp.k1 * dx[q - 9] + dx[q - 6]);
         else if (q == 12) a += dx[12] + d * (1 - gl) * du[6 * NV + 6];
         else if (q < 16) a += dx[q] + d * (1 - gl) * du[6 * NV + q - 13];
         else if (q == 16) a += dx[16] + d * (1 - gr) * du[6 * NV + 7];
         else if (q < 20) a += dx[q] + d * (1 - gr) * du[6 * NV + 3 + q - 17];
         else a += du[3 * (q - 20) + 2];
         gdx[(size_t)(k + 1) * NXA + q] = a;
-        L(D::oXN1 + q) = a;
+        L(nxt + q) = a;
       }
-      CMPC_SYNC();                             // every lane has read dx_k
-      if (lane < NXA) L(D::oXK + lane) = L(D::oXN1 + lane);
       CMPC_SYNC();
+      { const int t = cur; cur = nxt; nxt = t; }
       CMPC_TICK(18);
     }
   }
