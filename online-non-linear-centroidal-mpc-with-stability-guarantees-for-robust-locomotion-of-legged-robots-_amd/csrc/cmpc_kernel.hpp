@@ -99,6 +99,10 @@ constexpr int POLISH_ITERS = 2;
 constexpr double MU_INIT = 100.0;
 constexpr double MU_FACTOR = 0.1;
 
+#ifndef CMPC_NO_DEVICE_CODE
+#include "cmpc_lds_asm.hpp"
+#endif
+
 template <int NV> struct Dims {
   static constexpr int NF = 2 * NV;           // contact vertices
   static constexpr int NU = 6 * NV + 8;
@@ -143,12 +147,13 @@ template <int NV> struct Dims {
   static constexpr int oH1 = oH0 + NZ;
   static constexpr int oPC1 = oH1 + NZ;       // mu-coefficient of the cost-to-go gradient (NXA)
   static constexpr int oRED = oPC1 + NXA;     // 4 scratch slots
+  static constexpr int oDUMP = oRED + 4;      // one write-only slot per lane: target of masked-off read-modify-writes
   // The staging tile of T = P [B A] (NXA x TS) aliases the per-stage evaluation vectors
   // [oSK, oTV + NZ) when it fits (nv = 4): all of them are dead between build_H and the next
   // stage's load.  Otherwise (nv = 8) it gets its own region.
   static constexpr bool T_ALIAS = (oSK + NXA * TS <= oTV + NZ);
-  static constexpr int oT = T_ALIAS ? oSK : oRED + 4;
-  static constexpr int LDS_DOUBLES = T_ALIAS ? oRED + 4 : oRED + 4 + NXA * TS;
+  static constexpr int oT = T_ALIAS ? oSK : oDUMP + 64;
+  static constexpr int LDS_DOUBLES = T_ALIAS ? oDUMP + 64 : oDUMP + 64 + NXA * TS;
   // ---- global scratch map per stage (doubles) ----
   static constexpr int gLAM = 0;
   // Ls (NXA x NU) and P_k (NXA x NXA) as the forward sweep reads them, column c of both in one
@@ -694,7 +699,8 @@ template <int NV> struct Solver {
     // Register-blocked in small tiles: within a tile every LDS read is independent of the others (one
     // wave per SIMD has nothing else to hide the ~100-cycle LDS latency behind), and the tiles are
     // small enough (<= 2 x 14 doubles live) that the allocator does not serialise the reads.
-    constexpr int QT = (NXA % 2 == 0) ? NXA / 2 : NXA;          // rows of T per tile
+    constexpr int QT = (NXA <= 28) ? NXA : NXA / 2;             // rows of T per tile
+    static_assert(QT == 28 || QT == 18 || QT == 14, "LDS batch-read helper sizes");
     constexpr int CT = 10;                                      // columns of M per tile
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
@@ -711,9 +717,13 @@ template <int NV> struct Solver {
 #pragma unroll
             for (int n = 0; n < 6; ++n) {
               const double g = lg[h][n];
+              double v[QT];
               const double *pc = &L(D::oP + q0 * D::PS + lr[h][n]);
+              if constexpr (QT == 28) lds_read_strided28<D::PS>(v, pc);
+              else if constexpr (QT == 18) lds_read_strided18<D::PS>(v, pc);
+              else lds_read_strided14<D::PS>(v, pc);
 #pragma unroll
-              for (int q = 0; q < QT; ++q) acc[q] += g * pc[q * D::PS];
+              for (int q = 0; q < QT; ++q) acc[q] += g * v[q];
             }
             double *tc = &L(D::oT + q0 * D::TS + (col - c0));
 #pragma unroll
@@ -734,16 +744,22 @@ template <int NV> struct Solver {
 #pragma unroll
             for (int i = 0; i < CT; ++i) acc[i] = 0.0;
 #pragma unroll
-            for (int n = 0; n < 6; ++n) {
-              const double g = lg[h][n];
-              const double *tr = &L(D::oT + lr[h][n] * D::TS + i0);
+            for (int n = 0; n < 6; n += 2) {   // tail columns read valid LDS, results unused
+              const double g0 = lg[h][n], g1 = lg[h][n + 1];
+              double va[CT], vb[CT];
+              lds_read_pair10(va, vb, &L(D::oT + lr[h][n] * D::TS + i0), &L(D::oT + lr[h][n + 1] * D::TS + i0));
 #pragma unroll
-              for (int i = 0; i < CT; ++i) acc[i] += g * tr[i];   // tail columns read valid LDS, results unused
+              for (int i = 0; i < CT; ++i) acc[i] += g0 * va[i] + g1 * vb[i];
             }
-            double *row = &L(D::oM + tri(rowi) + c0 + i0);
+            // masked-off columns are redirected to the lane's dump slot: per-element conditional
+            // stores compile to a divergent branch with an exposed LDS round trip each
+            double *row = &L(D::oM + tri(rowi) + c0 + i0), *dump = &L(D::oDUMP + lane);
+            double *pm[CT];
+            double old[CT];
 #pragma unroll
-            for (int i = 0; i < CT; ++i)
-              if (i0 + i <= iend) row[i] += acc[i];
+            for (int i = 0; i < CT; ++i) { pm[i] = (i0 + i <= iend) ? row + i : dump; old[i] = *pm[i]; }
+#pragma unroll
+            for (int i = 0; i < CT; ++i) *pm[i] = old[i] + acc[i];
           }
         }
       }
@@ -860,6 +876,9 @@ template <int NV> struct Solver {
 #pragma unroll
         for (int cb = 0; cb <= rb; ++cb) acc[rb][cb] = CMPC_MFMA_F64(a[rb], a[cb], acc[rb][cb]);
     }
+    double *dump = &L(D::oDUMP + lane);
+    double *pm[NBR][NBR][4];
+    double old[NBR][NBR][4];
 #pragma unroll
     for (int rb = 0; rb < NBR; ++rb)
 #pragma unroll
@@ -867,8 +886,15 @@ template <int NV> struct Solver {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = R0 + 16 * rb + kq + 4 * r, j = R0 + 16 * cb + r16;   // D row / column of this component
-          if (i < NZ && j <= i) M[tri(i) + j] -= acc[rb][cb][r];
+          pm[rb][cb][r] = (i < NZ && j <= i) ? M + tri(i) + j : dump;
+          old[rb][cb][r] = *pm[rb][cb][r];
         }
+#pragma unroll
+    for (int rb = 0; rb < NBR; ++rb)
+#pragma unroll
+      for (int cb = 0; cb <= rb; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *pm[rb][cb][r] = old[rb][cb][r] - acc[rb][cb][r];
     CMPC_SYNC();
     return true;
   }
