@@ -565,133 +565,150 @@ template <int NV> struct Solver {
 #pragma unroll 1
     for (int h_ = 0; h_ < NH; ++h_) build_H_row(k, reg, lane + 64 * h_);
   }
-  CMPC_DEV void build_H_row(int k, double reg, const int i) {
-    if (i >= NZ) return;
-    double *row = &L(D::oM + tri(i));
-    for (int j = 0; j <= i; ++j) row[j] = 0.0;
+  // One pass over the columns, the same instruction stream for every row: the column type (force
+  // axis / foot, velocity, state group) is wave-uniform, everything that depends on the row is a
+  // per-lane coefficient computed up front, and entries right of the diagonal are redirected to the
+  // lane's dump slot instead of being branched around.  No LDS read-modify-write, no zero fill.
+  CMPC_DEV void build_H_row(int k, double reg, const int irow) {
+    const bool live = irow < NZ;
+    const int i = live ? irow : 0;              // idle lanes shadow row 0 and write only to the dump slot
+    const int wlim = live ? i : 0;              // columns j < wlim are written
+    double *row = &L(D::oM + tri(i)), *dump = &L(D::oDUMP + lane);
     const double m = L(D::oHDR + 20), muf = L(D::oHDR + 21);
     const double *x = &L(D::oXK);
     const double *sig = &L(D::oW0);
-    const double sigL = sig[R_LYAP], zL = L(D::oZK + R_LYAP) * ((k < N) ? 1.0 : 0.0);
+    const double *al = &L(D::oAL);
+    const bool stage = k < N;
+    const double sigL = sig[R_LYAP], zL = stage ? L(D::oZK + R_LYAP) : 0.0;
     const double d = sp.delta, k1 = sp.k1;
+    const double gam[2] = {L(D::oSR + 17), L(D::oSR + 18)};
     // Lyapunov quadratic-form coefficients hq (4x4 over c, v, theta, V)
     const double a1[4] = {1, d, 0, 0}, a2[4] = {k1, k1 * d + 1, 0, d};
     const double aS[4] = {0, 0, 1.0 / m, 1};
-    // type/axis/scale of an index for the Lyapunov terms: t = 0 c, 1 v, 2 theta, 3 V(force), -1 none
-    auto lyt = [&](int idx, int &t, int &a, double &sc) {
-      t = -1; a = 0; sc = 0.0;
-      if (idx < 6 * NV) { t = 3; a = idx % 3; sc = L(D::oSR + 17 + (idx / 3) / NV) / m; }
-      else if (idx >= NU && k >= 1) {
-        const int s = idx - NU;
-        if (s < 3) { t = 0; a = s; sc = 1.0; } else if (s < 6) { t = 1; a = s - 3; sc = 1.0; }
-        else if (s >= 9 && s < 12) { t = 2; a = s - 9; sc = 1.0; }
-      }
-    };
     auto hq = [&](int p, int q) {
       return -2 * k1 * a1[p] * a1[q] + 2 * k1 * a2[p] * a2[q] + (1 - k1 * k1) * (a1[p] * a2[q] + a2[p] * a1[q]) +
              a2[p] * aS[q] + aS[p] * a2[q];
     };
-    double diag = reg;
-    if (i < NU) {
-      if (k < N) {
-        diag += sp.prox;
-        if (i < 6 * NV) {
-          const int vtx = i / 3, a = i % 3, f = vtx / NV, jv = vtx % NV;
-          const double g1 = L(D::oSR + 17 + f);
-          const double a_ = g1 * g1 / NV, coef = NV * a_ * a_ - 2 * a_;
-          const double wa = sp.w_force * g1, wb = sp.w_force * (1 - g1);
-          diag += 2 * wa + 2 * wb + 2 * wa * coef;
-          for (int l = 0; l < jv; ++l) row[3 * (f * NV + l) + a] += 2 * wa * coef;   // mean-force coupling
-          if (a == 2 && k >= 1) diag += 2 * sp.w_rate * gam_km1(f);
-          // friction-cone barrier block of this vertex
-          const double *sr5 = sig + R_FRIC + 5 * vtx;
-          const double g2 = g1 * g1;
-          if (a == 0) diag += g2 * (sr5[0] + sr5[1]);
-          else if (a == 1) diag += g2 * (sr5[2] + sr5[3]);
-          else {
-            diag += g2 * (muf * muf * (sr5[0] + sr5[1] + sr5[2] + sr5[3]) + sr5[4]);
-            row[3 * vtx + 0] += -g2 * muf * (sr5[0] - sr5[1]);
-            row[3 * vtx + 1] += -g2 * muf * (sr5[2] - sr5[3]);
-          }
-        }
-      } else diag += 1.0;                              // no inputs at the terminal node
+    // ---- row role ----
+    const bool is_force = i < 6 * NV, is_state = i >= NU;
+    const int s = i - NU;                       // state index (state rows)
+    const int vtx_i = is_force ? i / 3 : 0, a_i = i % 3, f_i = vtx_i / NV;
+    int ti = -1, ai = 0; double sci = 0.0;     // Lyapunov role: 0 c, 1 v, 2 theta, 3 V (force)
+    if (stage) {
+      if (is_force) { ti = 3; ai = a_i; sci = gam[f_i] / m; }
+      else if (is_state && k >= 1) {
+        if (s < 3) { ti = 0; ai = s; sci = 1.0; } else if (s < 6) { ti = 1; ai = s - 3; sci = 1.0; }
+        else if (s >= 9 && s < 12) { ti = 2; ai = s - 9; sci = 1.0; }
+      }
+    }
+    const int tic = (ti >= 0) ? ti : 0;
+    const double sA = (ti >= 0) ? sigL * al[i] : 0.0;
+    const double hV = (ti >= 0) ? zL * hq(tic, 3) * sci / m : 0.0;       // against a force column of the same axis
+    double zq[3];                                                        // against a c / v / theta column of the same axis
+#pragma unroll
+    for (int t = 0; t < 3; ++t) zq[t] = (ti >= 0) ? zL * hq(tic, t) * sci : 0.0;
+    // dynamics curvature  pi . d2 tau  of this row against a force column (foot f, axis a, vertex offsets dvx, dvy):
+    //   gm[f] * (cc0[a] + ccx[a] * dvx + ccy[a] * dvy)
+    const double p0 = L(D::oMISC + 9), p1 = L(D::oMISC + 10), p2 = L(D::oMISC + 11);
+    const double Spm[3][3] = {{0.0, -p2, p1}, {p2, 0.0, -p0}, {-p1, p0, 0.0}};   // skew(pi)
+    const int ctype = (!stage || !is_state) ? 0 : (s < 3) ? 1 : (((s >= 13 && s < 16) || (s >= 17 && s < 20)) ? 2 : ((s == 12 || s == 16) ? 3 : 0));
+    const int cfoot = (s >= 16) ? 1 : 0, caxis = (s < 3) ? s : ((s >= 13) ? (s - 13) % 4 : 0);
+    const int cax = (caxis < 3) ? caxis : 0;
+    double cc0[3], ccx[3], ccy[3], gm[2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double spc = (cax == 0) ? Spm[a][0] : (cax == 1) ? Spm[a][1] : Spm[a][2];
+      cc0[a] = (ctype == 1) ? -spc : (ctype == 2) ? spc : 0.0;
+      ccx[a] = (ctype == 3) ? Spm[a][0] : 0.0;
+      ccy[a] = (ctype == 3) ? Spm[a][1] : 0.0;
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) gm[f] = (ctype == 1 || (ctype >= 2 && f == cfoot)) ? gam[f] : 0.0;
+    // force rows: mean-force coupling (same foot, same axis) and the friction block of the row's vertex
+    double mean_c = 0.0, fr0 = 0.0, fr1 = 0.0, diag = reg;
+    const double *sr5 = sig + R_FRIC + 5 * vtx_i;
+    if (stage && is_force) {
+      const double g1 = gam[f_i];
+      const double a_ = g1 * g1 / NV, coef = NV * a_ * a_ - 2 * a_;
+      const double wa = sp.w_force * g1, wb = sp.w_force * (1 - g1);
+      mean_c = 2 * wa * coef;
+      diag += 2 * wa + 2 * wb + mean_c;
+      if (a_i == 2 && k >= 1) diag += 2 * sp.w_rate * gam_km1(f_i);
+      const double g2 = g1 * g1;
+      if (a_i == 0) diag += g2 * (sr5[0] + sr5[1]);
+      else if (a_i == 1) diag += g2 * (sr5[2] + sr5[3]);
+      else {
+        diag += g2 * (muf * muf * (sr5[0] + sr5[1] + sr5[2] + sr5[3]) + sr5[4]);
+        fr0 = -g2 * muf * (sr5[0] - sr5[1]);
+        fr1 = -g2 * muf * (sr5[2] - sr5[3]);
+      }
+    }
+    const int j_fr0 = (stage && is_force && a_i == 2) ? 3 * vtx_i : -1;            // columns of fr0 / fr1
+    // carried-force rows: rate coupling with the f_z column of the same vertex
+    const bool is_fp = is_state && s >= CMPC_NX;
+    const double wr_fp = (is_fp && k >= 1 && stage) ? sp.w_rate * gam_km1((s - CMPC_NX) / NV) : 0.0;
+    const int j_fp = (is_fp && k >= 1 && stage) ? 3 * (s - CMPC_NX) + 2 : -1;
+    // constant part per (foot, axis) of a force column
+    double cst[2][3];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        cst[f][a] = ((a == ai) ? hV * gam[f] : 0.0) + ((is_force && f == f_i && a == a_i) ? mean_c : 0.0) + gm[f] * cc0[a];
+    // ---- force columns ----
+#pragma unroll 2
+    for (int v = 0; v < NF; ++v) {
+      const int f = v / NV;
+      const double dvx = L(D::oVDV + 3 * v), dvy = L(D::oVDV + 3 * v + 1);
+      const double cf0 = f ? cst[1][0] : cst[0][0], cf1 = f ? cst[1][1] : cst[0][1], cf2 = f ? cst[1][2] : cst[0][2];
+      const double gmf = f ? gm[1] : gm[0];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int j = 3 * v + a;
+        double val = sA * al[j] + ((a == 0) ? cf0 : (a == 1) ? cf1 : cf2) + gmf * (ccx[a] * dvx + ccy[a] * dvy);
+        if (a < 2) val += (j == j_fr0 + a) ? ((a == 0) ? fr0 : fr1) : 0.0;
+        if (a == 2) val += (j == j_fp) ? -2 * wr_fp : 0.0;
+        if (j == i) diag += sA * al[j] + hV * gam[f];                    // Lyapunov part of a force row's diagonal
+        *((j < wlim) ? row + j : dump) = val;
+      }
+    }
+    // ---- foot velocity columns: proximal term only ----
+#pragma unroll
+    for (int j = 6 * NV; j < NU; ++j) *((j < wlim) ? row + j : dump) = 0.0;
+    // ---- state columns ----
+    const bool hwc_row = (k == 1) && is_state && s >= 6 && s < 9;
+    const double hwc_c = hwc_row ? 4 * sig[R_HWC] * x[(s >= 6 && s < 9) ? s : 6] : 0.0;
+#pragma unroll
+    for (int sj = 0; sj < 12; ++sj) {
+      const int j = NU + sj;
+      const int tj = (sj < 3) ? 0 : (sj < 6) ? 1 : (sj >= 9) ? 2 : -1, aj = sj % 3;
+      double val = 0.0;
+      if (tj >= 0) {
+        val = sA * al[j] + ((aj == ai) ? zq[tj] : 0.0);
+        if (j == i) diag += val;
+      } else val = hwc_c * x[sj];
+      *((j < wlim) ? row + j : dump) = val;
+    }
+#pragma unroll 4
+    for (int j = NU + 12; j < NZ; ++j) *((j < wlim) ? row + j : dump) = 0.0;
+    // ---- diagonal ----
+    if (!is_state) {
+      if (stage) { if (!is_force) diag += 0.0; diag += sp.prox; } else diag = reg + 1.0;   // no inputs at the terminal node
     } else {
-      const int s = i - NU;
       if (k >= 1) {
         if (s < 3) { diag += 2 * ((s == 2) ? w_cz(k - 1) : sp.w_cxy); if (s == 2) diag += sig[R_CZ]; }
         else if (s >= 6 && s < 9) {
-          if (k < N) diag += 2 * sp.w_hw;
-          if (k == 1) {
-            diag += 2 * L(D::oZK + R_HWC) + 4 * sig[R_HWC] * x[s] * x[s];
-            for (int b = 6; b < s; ++b) row[NU + b] += 4 * sig[R_HWC] * x[s] * x[b];
-          }
+          if (stage) diag += 2 * sp.w_hw;
+          if (k == 1) diag += 2 * L(D::oZK + R_HWC) + 4 * sig[R_HWC] * x[s] * x[s];
         } else if (s == 12 || s == 16) { const double g = gam_k(k, s == 16); diag += 2 * sp.w_foot * g * g; }
         else if ((s >= 13 && s < 16) || (s >= 17 && s < 20)) {
           const int f = (s >= 17), a = (s - 13) % 4; const double g = gam_k(k, f);
           diag += 2 * sp.w_foot * g * g + g * g * (sig[R_BOX + 6 * f + 2 * a] + sig[R_BOX + 6 * f + 2 * a + 1]);
-        } else if (s >= CMPC_NX && k < N) {
-          const int vtx = s - CMPC_NX, f = vtx / NV;
-          const double wr = sp.w_rate * gam_km1(f);
-          diag += 2 * wr;
-          row[3 * vtx + 2] += -2 * wr;
-        }
+        } else if (is_fp && stage) diag += 2 * wr_fp;
       }
-      if (k < N) {                                      // dynamics curvature  pi . d2 tau
-        const double p0 = L(D::oMISC + 9), p1 = L(D::oMISC + 10), p2 = L(D::oMISC + 11);
-        auto Sp = [&](int a, int b) -> double {       // skew(pi)[a][b]
-          if (a == b) return 0.0;
-          if (a == 0) return (b == 1) ? -p2 : p1;
-          if (a == 1) return (b == 0) ? p2 : -p0;
-          return (b == 0) ? -p1 : p0;
-        };
-        if (s < 3) {
-          for (int v = 0; v < NF; ++v) {
-            const double g = L(D::oSR + 17 + v / NV);
-            for (int a = 0; a < 3; ++a) row[3 * v + a] += -g * Sp(a, s);
-          }
-        } else if ((s >= 13 && s < 16) || (s >= 17 && s < 20)) {
-          const int f = (s >= 17), b = (s - 13) % 4; const double g = L(D::oSR + 17 + f);
-          for (int j = 0; j < NV; ++j) for (int a = 0; a < 3; ++a) row[3 * (f * NV + j) + a] += g * Sp(a, b);
-        } else if (s == 12 || s == 16) {
-          const int f = (s == 16); const double g = L(D::oSR + 17 + f);
-          for (int j = 0; j < NV; ++j) {
-            const int v = f * NV + j;
-            const double dx_ = L(D::oVDV + 3 * v), dy_ = L(D::oVDV + 3 * v + 1);
-            for (int a = 0; a < 3; ++a) row[3 * v + a] += g * (Sp(a, 0) * dx_ + Sp(a, 1) * dy_);
-          }
-          diag += L(D::oMISC + 30 + f);
-        }
-      }
+      if (ctype == 3) diag += L(D::oMISC + 30 + cfoot);
     }
-    // Lyapunov: barrier rank-1 + multiplier-weighted constant Hessian
-    if (k < N) {
-      int ti, ai; double sci;
-      lyt(i, ti, ai, sci);
-      if (ti >= 0) {
-        const double ali = L(D::oAL + i);
-        const double sA = sigL * ali;
-        const double hV = zL * hq(ti, 3) * sci / m;     // against a force column of the same axis
-        const double gl_ = L(D::oSR + 17), gr_ = L(D::oSR + 18);
-        const int jf = (i < 6 * NV) ? i : 6 * NV - 1;   // force columns j <= i
-        for (int j = 0; j <= jf; ++j) {
-          double v = sA * L(D::oAL + j);
-          if (j % 3 == ai) v += hV * ((j < 3 * NV) ? gl_ : gr_);
-          if (j == i) diag += v; else row[j] += v;
-        }
-        if (i >= NU) {                                  // state columns c, v, theta (k >= 1 here)
-          const int so[3] = {0, 3, 9};
-          for (int t = 0; t < 3; ++t)
-            for (int a = 0; a < 3; ++a) {
-              const int j = NU + so[t] + a;
-              if (j > i) continue;
-              double v = sA * L(D::oAL + j);
-              if (a == ai) v += zL * hq(ti, t) * sci;
-              if (j == i) diag += v; else row[j] += v;
-            }
-        }
-      }
-    }
-    row[i] += diag;
+    if (live) row[i] = diag;
   }
 
   // M += [B A]' P [B A]  (lower triangle, row owner), using T = P [B A] staged by column halves.
