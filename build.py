@@ -16,7 +16,8 @@ def _newer(target, sources):
 
 def build_hip(force=False, verbose=False):
     src = os.path.join(PKG, "csrc", "cmpc_hip.hip")
-    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(ROOT, "include", "cmpc.h")]
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"),
+            os.path.join(ROOT, "include", "cmpc.h")]
     out = os.path.join(PKG, "libcmpc_amd.so")
     if force or _newer(out, deps):
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out, src]
@@ -29,7 +30,8 @@ def build_hip(force=False, verbose=False):
 def build_hip_profile(force=False):
     """Diagnostic variant with in-kernel phase timers (tools/ only; never loaded by the package)."""
     src = os.path.join(PKG, "csrc", "cmpc_hip.hip")
-    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(ROOT, "include", "cmpc.h")]
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"),
+            os.path.join(ROOT, "include", "cmpc.h")]
     out = os.path.join(ROOT, "tools", "libcmpc_amd_prof.so")
     if force or _newer(out, deps):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -49,7 +51,8 @@ def build_oracle(force=False):
 def build_emu(force=False):
     src = os.path.join(ROOT, "tests", "emu", "cmpc_emu.cpp")
     out = os.path.join(ROOT, "tests", "emu", "libcmpc_emu.so")
-    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(ROOT, "include", "cmpc.h")]
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"),
+            os.path.join(ROOT, "include", "cmpc.h")]
     if force or _newer(out, deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", out, src])
     return out

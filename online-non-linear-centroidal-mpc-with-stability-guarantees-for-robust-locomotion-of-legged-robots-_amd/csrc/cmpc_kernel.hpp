@@ -103,6 +103,30 @@ constexpr double MU_FACTOR = 0.1;
 #include "cmpc_lds_asm.hpp"
 #endif
 
+#ifndef CMPC_NO_DEVICE_CODE
+// v[0..CNT) = p[0..CNT) (LDS), in batches of independent reads
+template <int CNT> CMPC_DEV void lds_read_row(double (&v)[CNT], const double *p) {
+  static_assert(CNT == 28 || CNT == 32 || CNT == 36 || CNT == 56, "supported row lengths");
+  if constexpr (CNT == 28) lds_read_strided28<1>(v, p);
+  else if constexpr (CNT == 32) {
+    double a[16], b[16];
+    lds_read_strided16<1>(a, p); lds_read_strided16<1>(b, p + 16);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v[i] = a[i]; v[16 + i] = b[i]; }
+  } else if constexpr (CNT == 36) {
+    double a[18], b[18];
+    lds_read_strided18<1>(a, p); lds_read_strided18<1>(b, p + 18);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { v[i] = a[i]; v[18 + i] = b[i]; }
+  } else {
+    double a[28], b[28];
+    lds_read_strided28<1>(a, p); lds_read_strided28<1>(b, p + 28);
+#pragma unroll
+    for (int i = 0; i < 28; ++i) { v[i] = a[i]; v[28 + i] = b[i]; }
+  }
+}
+#endif
+
 template <int NV> struct Dims {
   static constexpr int NF = 2 * NV;           // contact vertices
   static constexpr int NU = 6 * NV + 8;
@@ -656,19 +680,24 @@ template <int NV> struct Solver {
       for (int a = 0; a < 3; ++a)
         cst[f][a] = ((a == ai) ? hV * gam[f] : 0.0) + ((is_force && f == f_i && a == a_i) ? mean_c : 0.0) + gm[f] * cc0[a];
     // ---- force columns ----
-#pragma unroll 2
+    double alf[6 * NV], dvv[6 * NV];            // Lyapunov gradient and R'v_j of the force columns, one batch each
+    if constexpr (NV == 4) { lds_read_strided14<1>(*(double (*)[14])&alf[0], al); lds_read_strided14<1>(*(double (*)[14])&alf[10], al + 10);
+                             lds_read_strided14<1>(*(double (*)[14])&dvv[0], &L(D::oVDV)); lds_read_strided14<1>(*(double (*)[14])&dvv[10], &L(D::oVDV + 10)); }
+    else { lds_read_strided28<1>(*(double (*)[28])&alf[0], al); lds_read_strided28<1>(*(double (*)[28])&alf[20], al + 20);
+           lds_read_strided28<1>(*(double (*)[28])&dvv[0], &L(D::oVDV)); lds_read_strided28<1>(*(double (*)[28])&dvv[20], &L(D::oVDV + 20)); }
+#pragma unroll
     for (int v = 0; v < NF; ++v) {
       const int f = v / NV;
-      const double dvx = L(D::oVDV + 3 * v), dvy = L(D::oVDV + 3 * v + 1);
+      const double dvx = dvv[3 * v], dvy = dvv[3 * v + 1];
       const double cf0 = f ? cst[1][0] : cst[0][0], cf1 = f ? cst[1][1] : cst[0][1], cf2 = f ? cst[1][2] : cst[0][2];
       const double gmf = f ? gm[1] : gm[0];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const int j = 3 * v + a;
-        double val = sA * al[j] + ((a == 0) ? cf0 : (a == 1) ? cf1 : cf2) + gmf * (ccx[a] * dvx + ccy[a] * dvy);
+        double val = sA * alf[j] + ((a == 0) ? cf0 : (a == 1) ? cf1 : cf2) + gmf * (ccx[a] * dvx + ccy[a] * dvy);
         if (a < 2) val += (j == j_fr0 + a) ? ((a == 0) ? fr0 : fr1) : 0.0;
         if (a == 2) val += (j == j_fp) ? -2 * wr_fp : 0.0;
-        if (j == i) diag += sA * al[j] + hV * gam[f];                    // Lyapunov part of a force row's diagonal
+        if (j == i) diag += sA * alf[j] + hV * gam[f];                   // Lyapunov part of a force row's diagonal
         *((j < wlim) ? row + j : dump) = val;
       }
     }
@@ -678,13 +707,15 @@ template <int NV> struct Solver {
     // ---- state columns ----
     const bool hwc_row = (k == 1) && is_state && s >= 6 && s < 9;
     const double hwc_c = hwc_row ? 4 * sig[R_HWC] * x[(s >= 6 && s < 9) ? s : 6] : 0.0;
+    double als[14];                             // al / x of the 12 leading state columns (c, v, hw, theta)
+    lds_read_strided14<1>(als, al + NU);
 #pragma unroll
     for (int sj = 0; sj < 12; ++sj) {
       const int j = NU + sj;
       const int tj = (sj < 3) ? 0 : (sj < 6) ? 1 : (sj >= 9) ? 2 : -1, aj = sj % 3;
       double val = 0.0;
       if (tj >= 0) {
-        val = sA * al[j] + ((aj == ai) ? zq[tj] : 0.0);
+        val = sA * als[sj] + ((aj == ai) ? zq[tj] : 0.0);
         if (j == i) diag += val;
       } else val = hwc_c * x[sj];
       *((j < wlim) ? row + j : dump) = val;
@@ -795,77 +826,104 @@ template <int NV> struct Solver {
   // 16x16 tiles of v_mfma_f64_16x16x4; the product is L21 L21', so the B operand of column block cb is
   // the A operand of row block cb.  After the last block the state-state corner of M is
   // P_k = M_xx - Ls Ls' (the Schur complement) without a separate pass.
+  // sqrt(p) and 1/sqrt(p) of a pivot by coupled Newton iterations on the hardware estimate: the
+  // library sqrt followed by a division is a ~40-instruction dependent chain (special-case scaling
+  // and fix-ups), and there are NU of them per stage on the critical path.  p > 1e-14 here.
+  CMPC_DEV static void pivot_sqrt(double p, double &s, double &inv) {
+#ifdef CMPC_HOST_EMU
+    s = sqrt(p); inv = 1.0 / s;
+#else
+    const double y = __builtin_amdgcn_rsq(p);
+    double g = p * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    const double dd = __builtin_fma(-g, g, p);
+    s = __builtin_fma(dd, h, g);
+    inv = h + h;
+#endif
+  }
   template <int C0> CMPC_DEV bool chol_block(double *M, bool &ok, bool trailing) {
     constexpr int W = (NU - C0 < 16) ? NU - C0 : 16;
     static_assert(W % 4 == 0, "block width is a multiple of the 4-column panel");
-    for (int J = C0; J < C0 + W; J += 4) {
-      const double *r0 = M + tri(J), *r1 = M + tri(J + 1), *r2 = M + tri(J + 2), *r3 = M + tri(J + 3);
-      double l0v[NH], l1v[NH], l2v[NH], l3v[NH];
-      double t10 = 0, t20 = 0, t21 = 0, t30 = 0, t31 = 0, t32 = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    // (1) The block's W columns of every row at or below the block live in registers while the block is
+    // factorised: pivots and multipliers travel by readlane (the panel rows are lanes C0..C0+W-1 of the
+    // first row set), so there is no LDS traffic and no barrier inside the block.
+    double blk[NH][W];
+    double *dump = &L(D::oDUMP + lane);
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int rowi = lane + 64 * h;
-        const bool own = rowi >= J && rowi < NZ;
-        const int li = own ? rowi : J + 3;    // idle lanes shadow a valid row; their results are never stored
-        const double *ri = M + tri(li);
-        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-#pragma unroll 4
-        for (int q = C0; q < J; ++q) {                 // earlier blocks were applied by the trailing updates
-          const double x = ri[q];
-          d0 += x * r0[q]; d1 += x * r1[q]; d2 += x * r2[q]; d3 += x * r3[q];
-        }
-        // entries above the diagonal of rows J..J+2 do not exist: read a harmless in-row word instead
-        const int c1i = (li >= J + 1) ? J + 1 : J, c2i = (li >= J + 2) ? J + 2 : J, c3i = (li >= J + 3) ? J + 3 : J;
-        double a0 = ri[J] - d0, a1 = ri[c1i] - d1, a2 = ri[c2i] - d2, a3 = ri[c3i] - d3;
-        if (h == 0) {                          // the panel itself: pivots and multipliers by readlane
-          const double p0 = CMPC_BCAST(a0, J);
-          ok = ok && (p0 > 1e-14);
-          const double s0 = sqrt(p0); i0 = 1.0 / s0;
-          const double l0 = (lane == J) ? s0 : a0 * i0;
-          t10 = CMPC_BCAST(l0, J + 1);
-          a1 -= l0 * t10;
-          const double p1 = CMPC_BCAST(a1, J + 1);
-          ok = ok && (p1 > 1e-14);
-          const double s1 = sqrt(p1); i1 = 1.0 / s1;
-          const double l1 = (lane == J + 1) ? s1 : a1 * i1;
-          t20 = CMPC_BCAST(l0, J + 2); t21 = CMPC_BCAST(l1, J + 2);
-          a2 -= l0 * t20 + l1 * t21;
-          const double p2 = CMPC_BCAST(a2, J + 2);
-          ok = ok && (p2 > 1e-14);
-          const double s2 = sqrt(p2); i2 = 1.0 / s2;
-          const double l2 = (lane == J + 2) ? s2 : a2 * i2;
-          t30 = CMPC_BCAST(l0, J + 3); t31 = CMPC_BCAST(l1, J + 3); t32 = CMPC_BCAST(l2, J + 3);
-          a3 -= l0 * t30 + l1 * t31 + l2 * t32;
-          const double p3 = CMPC_BCAST(a3, J + 3);
-          ok = ok && (p3 > 1e-14);
-          const double s3 = sqrt(p3); i3 = 1.0 / s3;
-          const double l3 = (lane == J + 3) ? s3 : a3 * i3;
-          l0v[0] = l0; l1v[0] = l1; l2v[0] = l2; l3v[0] = l3;
-        } else {                               // rows below the panel reuse the broadcast multipliers
-          const double l0 = a0 * i0;
-          a1 -= l0 * t10;
-          const double l1 = a1 * i1;
-          a2 -= l0 * t20 + l1 * t21;
-          const double l2 = a2 * i2;
-          a3 -= l0 * t30 + l1 * t31 + l2 * t32;
-          const double l3 = a3 * i3;
-          l0v[h] = l0; l1v[h] = l1; l2v[h] = l2; l3v[h] = l3;
-        }
+    for (int h = 0; h < NH; ++h) {
+      const int rowi = lane + 64 * h;
+      const bool own = rowi >= C0 && rowi < NZ;
+      const double *ri = M + tri(own ? rowi : C0) + C0;
+#pragma unroll
+      for (int c = 0; c < W; ++c) blk[h][c] = ri[(own && C0 + c <= rowi) ? c : 0];   // right of the diagonal: a harmless in-row word
+    }
+#pragma unroll
+    for (int p = 0; p < W / 4; ++p) {
+      const int J = C0 + 4 * p;
+      double t10, t20, t21, t30, t31, t32, i0, i1, i2, i3;
+      {                                        // the panel itself (first row set): pivots and multipliers by readlane
+        double a0 = blk[0][4 * p], a1 = blk[0][4 * p + 1], a2 = blk[0][4 * p + 2], a3 = blk[0][4 * p + 3];
+        const double p0 = CMPC_BCAST(a0, J);
+        ok = ok && (p0 > 1e-14);
+        double s0; pivot_sqrt(p0, s0, i0);
+        const double l0 = (lane == J) ? s0 : a0 * i0;
+        t10 = CMPC_BCAST(l0, J + 1);
+        a1 -= l0 * t10;
+        const double p1 = CMPC_BCAST(a1, J + 1);
+        ok = ok && (p1 > 1e-14);
+        double s1; pivot_sqrt(p1, s1, i1);
+        const double l1 = (lane == J + 1) ? s1 : a1 * i1;
+        t20 = CMPC_BCAST(l0, J + 2); t21 = CMPC_BCAST(l1, J + 2);
+        a2 -= l0 * t20 + l1 * t21;
+        const double p2 = CMPC_BCAST(a2, J + 2);
+        ok = ok && (p2 > 1e-14);
+        double s2; pivot_sqrt(p2, s2, i2);
+        const double l2 = (lane == J + 2) ? s2 : a2 * i2;
+        t30 = CMPC_BCAST(l0, J + 3); t31 = CMPC_BCAST(l1, J + 3); t32 = CMPC_BCAST(l2, J + 3);
+        a3 -= l0 * t30 + l1 * t31 + l2 * t32;
+        const double p3 = CMPC_BCAST(a3, J + 3);
+        ok = ok && (p3 > 1e-14);
+        double s3; pivot_sqrt(p3, s3, i3);
+        const double l3 = (lane == J + 3) ? s3 : a3 * i3;
+        blk[0][4 * p] = l0; blk[0][4 * p + 1] = l1; blk[0][4 * p + 2] = l2; blk[0][4 * p + 3] = l3;
+      }
+#pragma unroll
+      for (int h = 1; h < NH; ++h) {           // further row sets reuse the broadcast multipliers
+        const double l0 = blk[h][4 * p] * i0;
+        const double l1 = (blk[h][4 * p + 1] - l0 * t10) * i1;
+        const double l2 = (blk[h][4 * p + 2] - (l0 * t20 + l1 * t21)) * i2;
+        const double l3 = (blk[h][4 * p + 3] - (l0 * t30 + l1 * t31 + l2 * t32)) * i3;
+        blk[h][4 * p] = l0; blk[h][4 * p + 1] = l1; blk[h][4 * p + 2] = l2; blk[h][4 * p + 3] = l3;
       }
       if (!ok) return false;                   // pivots are wave-uniform
+      // right-looking inside the block: the remaining block columns of every row
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int rowi = lane + 64 * h;
-        if (rowi >= J && rowi < NZ) {
-          double *wi = M + tri(rowi) + J;
-          wi[0] = l0v[h];
-          if (rowi >= J + 1) wi[1] = l1v[h];
-          if (rowi >= J + 2) wi[2] = l2v[h];
-          if (rowi >= J + 3) wi[3] = l3v[h];
+      for (int cc = 4 * p + 4; cc < W; ++cc) {
+        const int jrow = C0 + cc;              // the row whose multipliers form column cc's update
+        const double u0 = CMPC_BCAST(blk[0][4 * p], jrow), u1 = CMPC_BCAST(blk[0][4 * p + 1], jrow);
+        const double u2 = CMPC_BCAST(blk[0][4 * p + 2], jrow), u3 = CMPC_BCAST(blk[0][4 * p + 3], jrow);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          double xv = blk[h][cc];
+          xv = __builtin_fma(-blk[h][4 * p], u0, xv); xv = __builtin_fma(-blk[h][4 * p + 1], u1, xv);
+          xv = __builtin_fma(-blk[h][4 * p + 2], u2, xv); xv = __builtin_fma(-blk[h][4 * p + 3], u3, xv);
+          blk[h][cc] = xv;
         }
       }
-      CMPC_SYNC();
     }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int rowi = lane + 64 * h;
+      const bool own = rowi >= C0 && rowi < NZ;
+      double *wi = M + tri(own ? rowi : C0) + C0;
+#pragma unroll
+      for (int c = 0; c < W; ++c) *((own && C0 + c <= rowi) ? wi + c : dump) = blk[h][c];
+    }
+    CMPC_SYNC();
+    CMPC_TICK(21);
     if (!trailing) return true;
     constexpr int R0 = C0 + W;                  // first trailing row / column
     constexpr int NBR = (NZ - R0 + 15) / 16;
@@ -893,7 +951,7 @@ template <int NV> struct Solver {
 #pragma unroll
         for (int cb = 0; cb <= rb; ++cb) acc[rb][cb] = CMPC_MFMA_F64(a[rb], a[cb], acc[rb][cb]);
     }
-    double *dump = &L(D::oDUMP + lane);
+    CMPC_TICK(22);
     double *pm[NBR][NBR][4];
     double old[NBR][NBR][4];
 #pragma unroll
@@ -944,10 +1002,17 @@ template <int NV> struct Solver {
     double *st = stage(k);
     const double *M = &L(D::oM);
     if (k < N) {
-      for (int e = lane; e < NU * NU; e += 64) {
-        const int i = e / NU, j = e % NU;
-        st[D::gLAM + e] = (j <= i) ? M[tri(i) + j] : 0.0;
+      constexpr int NLAM = (NU * NU) / 64;
+      static_assert((NU * NU) % 64 == 0, "whole passes");
+      double vl[NLAM];
+#pragma unroll
+      for (int q = 0; q < NLAM; ++q) {       // all LDS reads first (clamped addresses instead of branches)
+        const int e = lane + 64 * q, i = e / NU, j = e % NU;
+        const double v = M[tri(i) + ((j <= i) ? j : i)];
+        vl[q] = (j <= i) ? v : 0.0;
       }
+#pragma unroll
+      for (int q = 0; q < NLAM; ++q) st[D::gLAM + lane + 64 * q] = vl[q];
       if constexpr (!D::W_MERGE)
         for (int e = lane; e < NXA * NU; e += 64) {
           const int i = e / NU, j = e % NU;
@@ -957,9 +1022,12 @@ template <int NV> struct Solver {
     if constexpr (D::W_MERGE) {
       const bool a = lane < NU && k < N, b = lane >= NU && lane < NZ && k >= 1;
       if (a || b) {
-#pragma unroll 4
-        for (int c = 0; c < NXA; ++c)
-          st[D::gLS + c * 64 + lane] = a ? M[tri(NU + c) + lane] : L(D::oP + c * D::PS + lane - NU);
+        const double *src = a ? M + tri(NU) + lane : &L(D::oP + lane - NU);
+        double vw[NXA];
+#pragma unroll
+        for (int c = 0; c < NXA; ++c) vw[c] = src[a ? tri(NU + c) - tri(NU) : c * D::PS];
+#pragma unroll
+        for (int c = 0; c < NXA; ++c) st[D::gLS + c * 64 + lane] = vw[c];
       }
     } else if (k >= 1)
       for (int e = lane; e < NXA * NXA; e += 64) st[D::gPK + e] = L(D::oP + (e / NXA) * D::PS + (e % NXA));
@@ -987,34 +1055,50 @@ template <int NV> struct Solver {
       L(D::oTV + col) = a0; L(D::oAL + col) = a1;
     }
     CMPC_SYNC();
+    CMPC_TICK(2);
+    static_assert(NU % 2 == 0 && (NU / 2 == 16 || NU / 2 == 28), "half rows match the LDS batch-read helpers");
+    constexpr int HB = NU / 2;
+    double lf0, lf1;                           // l of this lane's row (lanes < NU)
     {                                          // l = L^-1 m_u for both right-hand sides at once
       const int li = (lane < NU) ? lane : NU - 1;
-      const double *ri = M + tri(li);
       double m0 = L(D::oTV + li), m1 = L(D::oAL + li);
-      const double dinv = 1.0 / ri[li];
-#pragma unroll 8
-      for (int j = 0; j < NU; ++j) {
-        const double l0j = CMPC_BCAST(m0 * dinv, j), l1j = CMPC_BCAST(m1 * dinv, j);
-        const double lij = ri[(j <= li) ? j : li];     // entries right of the diagonal do not exist
-        if (lane > j) { m0 -= lij * l0j; m1 -= lij * l1j; }
+      const double dinv = 1.0 / M[tri(li) + li];
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {         // own row of Lambda, half a row of registers at a time
+        double rr[HB];                         // (words right of the diagonal are read but never used)
+        if constexpr (HB == 16) lds_read_strided16<1>(rr, M + tri(li) + hb * HB);
+        else lds_read_strided28<1>(rr, M + tri(li) + hb * HB);
+#pragma unroll
+        for (int jj = 0; jj < HB; ++jj) {
+          const int j = hb * HB + jj;
+          const double l0j = CMPC_BCAST(m0 * dinv, j), l1j = CMPC_BCAST(m1 * dinv, j);
+          if (lane > j) { m0 -= rr[jj] * l0j; m1 -= rr[jj] * l1j; }
+        }
       }
-      if (lane < NU) {
-        L(D::oTV + lane) = m0 * dinv; L(D::oAL + lane) = m1 * dinv;
-        st[D::gL + lane] = m0 * dinv; st[D::gL1 + lane] = m1 * dinv;
-      }
+      lf0 = m0 * dinv; lf1 = m1 * dinv;
+      if (lane < NU) { st[D::gL + lane] = lf0; st[D::gL1 + lane] = lf1; }
     }
-    CMPC_SYNC();
-    if (lane < NXA) {                          // p = m_x - Ls l
-      const double *lsr = M + tri(NU + lane), *l0 = &L(D::oTV), *l1 = &L(D::oAL);
+    CMPC_TICK(3);
+    {                                          // p = m_x - Ls l, the entries of l by readlane
+      const int lx = (lane < NXA) ? lane : 0;
       double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
 #pragma unroll
-      for (int q = 0; q < NU; q += 2) {
-        a0 += lsr[q] * l0[q]; a1 += lsr[q + 1] * l0[q + 1];
-        b0 += lsr[q] * l1[q]; b1 += lsr[q + 1] * l1[q + 1];
+      for (int hb = 0; hb < 2; ++hb) {
+        double ls[HB];
+        if constexpr (HB == 16) lds_read_strided16<1>(ls, M + tri(NU + lx) + hb * HB);
+        else lds_read_strided28<1>(ls, M + tri(NU + lx) + hb * HB);
+#pragma unroll
+        for (int q = 0; q < HB; q += 2) {
+          const int j = hb * HB + q;
+          a0 += ls[q] * CMPC_BCAST(lf0, j); a1 += ls[q + 1] * CMPC_BCAST(lf0, j + 1);
+          b0 += ls[q] * CMPC_BCAST(lf1, j); b1 += ls[q + 1] * CMPC_BCAST(lf1, j + 1);
+        }
       }
-      const double p0 = L(D::oTV + NU + lane) - (a0 + a1), p1 = L(D::oAL + NU + lane) - (b0 + b1);
-      L(D::oPC + lane) = p0; L(D::oPC1 + lane) = p1;
-      st[D::gPV + lane] = p0; st[D::gPV1 + lane] = p1;
+      if (lane < NXA) {
+        const double p0 = L(D::oTV + NU + lane) - (a0 + a1), p1 = L(D::oAL + NU + lane) - (b0 + b1);
+        L(D::oPC + lane) = p0; L(D::oPC1 + lane) = p1;
+        st[D::gPV + lane] = p0; st[D::gPV1 + lane] = p1;
+      }
     }
     CMPC_SYNC();
   }
@@ -1127,12 +1211,12 @@ template <int NV> struct Solver {
 #ifndef CMPC_X_NO_GTPG
         add_GtPG();
 #endif
-        CMPC_TICK(2);
+        CMPC_TICK(15);
         CMPC_OPAQUE(lane);
 #ifndef CMPC_X_NO_FACTOR
         if (!factor_stage(k)) return false;
 #endif
-        CMPC_TICK(3);
+        CMPC_TICK(23);
         backward_vectors(k);
         CMPC_TICK(5);
       } else {

@@ -5,6 +5,9 @@ import numpy as np, torch
 import cmpc_amd
 from cmpc_amd import workloads as wl
 from cmpc_amd.solver import BatchedCentroidalMPC
+from cmpc_amd import capi as _capi
+if os.environ.get("CMPC_LIB"):
+    _capi.LIB_PATH = os.path.abspath(os.environ["CMPC_LIB"])   # developer variants
 from oracle import oracle_lib as ol
 
 name = sys.argv[1] if len(sys.argv) > 1 else "perturbed"
@@ -67,6 +70,6 @@ if os.environ.get("CMPC_PROF"):
     ps.solve(d_rec); torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 24)()
     ps._lib.cmpc_profile_read(ps._h, buf)
-    tot = float(sum(buf)); names = ["eval_rest", "build_H", "-", "-", "store", "bwd_vectors", "vec_fwd", "step", "chol", "schur", "GtPG_T", "load+geom", "ineq", "Pb", "GtPG_Mupd", "-", "fwd_load", "fwd_backsub", "fwd_dx", "fwd_lam", "step_len", "-", "-", "-"]
+    tot = float(sum(buf)); names = ["eval_rest", "build_H", "bwd_m", "bwd_lsolve", "store", "bwd_p", "vec_fwd", "step", "chol", "schur", "GtPG_T", "load+geom", "ineq", "Pb", "GtPG_Mupd", "-", "fwd_load", "fwd_backsub", "fwd_dx", "fwd_lam", "step_len", "chol_panels", "chol_mfma", "-"]
     print("phase cycles (sum over instances):", {n: "%.1f%%" % (100 * b / tot) for n, b in zip(names, buf)})
     print("cycles per instance-iteration: %.0f" % (tot / it.sum()))
