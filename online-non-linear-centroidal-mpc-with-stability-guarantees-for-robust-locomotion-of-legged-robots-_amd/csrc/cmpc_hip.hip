@@ -180,7 +180,7 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   h->slab_doubles = slab_doubles(spec);
 #ifdef CMPC_PROFILE
   (void)hipMalloc(&h->dbg, 65536 * sizeof(double));
-  if (hipMalloc(&h->prof, 24 * sizeof(long long)) == hipSuccess) (void)hipMemset(h->prof, 0, 24 * sizeof(long long));
+  if (hipMalloc(&h->prof, 28 * sizeof(long long)) == hipSuccess) (void)hipMemset(h->prof, 0, 28 * sizeof(long long));
 #endif
   if (hipMalloc(&h->scratch, (size_t)h->grid * h->slab_doubles * sizeof(double)) != hipSuccess ||
       hipMalloc(&h->ticket, sizeof(int)) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
@@ -299,8 +299,8 @@ int cmpc_debug_read(cmpc_handle *h, double *out, int n) {
 /* diagnostic build only: read and reset the phase cycle sums */
 int cmpc_profile_read(cmpc_handle *h, long long *out8) {
   if (!h || !h->prof) return 1;
-  if (hipMemcpy(out8, h->prof, 24 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return 1;
-  (void)hipMemset(h->prof, 0, 24 * sizeof(long long));
+  if (hipMemcpy(out8, h->prof, 28 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  (void)hipMemset(h->prof, 0, 28 * sizeof(long long));
   return 0;
 }
 #endif

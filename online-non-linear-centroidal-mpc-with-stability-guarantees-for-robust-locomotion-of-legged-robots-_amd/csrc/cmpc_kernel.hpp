@@ -229,7 +229,7 @@ template <int NV> struct Solver {
   // per-lane column list of [B A]: rows / coefficients (id, h0, h1, h2, sp1, sp2)
   int lr[NH][6];
   double lg[NH][6];
-  long long tprof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  long long tprof[28] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
   bool dbg_on = false;
 
   CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
@@ -314,53 +314,59 @@ template <int NV> struct Solver {
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void stage_geometry(int k) {
     const double d = sp.delta, m = L(D::oHDR + 20);
+    // (A) one lane per contact vertex: rotated offsets, lever arm, and the vertex's terms of every
+    // per-foot sum (torque r x f, yaw term (R'v) x f, yaw-yaw curvature) -- products staged in the
+    // H0/H1 block (written later in the sweep), summed in (B) by one lane per result.
+    double *tq = &L(D::oH0), *yw = &L(D::oH0 + 3 * NF), *qq = &L(D::oH0 + 6 * NF);
+    static_assert(7 * NF <= 2 * NZ, "vertex products fit the H0/H1 block");
     if (lane < NF) {
       const int f = lane / NV, j = lane % NV;
       const double yaw = L(D::oXK + 12 + 4 * f);
+      const double px = L(D::oXK + 13 + 4 * f), py = L(D::oXK + 14 + 4 * f), pz = L(D::oXK + 15 + 4 * f);
+      const double cx = L(D::oXK + 0), cy = L(D::oXK + 1), cz = L(D::oXK + 2);
+      const double fx = L(D::oUK + 3 * lane), fy = L(D::oUK + 3 * lane + 1), fz = L(D::oUK + 3 * lane + 2);
+#ifdef CMPC_NO_DYN_CURV
+      const double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+#else
+      const double p0 = d * L(D::oLAMN + 6), p1 = d * L(D::oLAMN + 7), p2 = d * L(D::oLAMN + 8);   // pi
+#endif
       const double cs = cos(yaw), sn = sin(yaw);
       double vx, vy; vert_local(j, vx, vy);
       const double rvx = cs * vx - sn * vy, rvy = sn * vx + cs * vy;
+      const double dvx = -sn * vx - cs * vy, dvy = cs * vx - sn * vy;
+      const double rx = px + rvx - cx, ry = py + rvy - cy, rz = pz - cz;
       L(D::oVRV + 3 * lane + 0) = rvx; L(D::oVRV + 3 * lane + 1) = rvy; L(D::oVRV + 3 * lane + 2) = 0.0;
-      L(D::oVDV + 3 * lane + 0) = -sn * vx - cs * vy; L(D::oVDV + 3 * lane + 1) = cs * vx - sn * vy;
-      L(D::oVDV + 3 * lane + 2) = 0.0;
-      L(D::oVR + 3 * lane + 0) = L(D::oXK + 13 + 4 * f + 0) + rvx - L(D::oXK + 0);
-      L(D::oVR + 3 * lane + 1) = L(D::oXK + 13 + 4 * f + 1) + rvy - L(D::oXK + 1);
-      L(D::oVR + 3 * lane + 2) = L(D::oXK + 13 + 4 * f + 2) - L(D::oXK + 2);
+      L(D::oVDV + 3 * lane + 0) = dvx; L(D::oVDV + 3 * lane + 1) = dvy; L(D::oVDV + 3 * lane + 2) = 0.0;
+      L(D::oVR + 3 * lane + 0) = rx; L(D::oVR + 3 * lane + 1) = ry; L(D::oVR + 3 * lane + 2) = rz;
+      tq[3 * lane + 0] = ry * fz - rz * fy; tq[3 * lane + 1] = rz * fx - rx * fz; tq[3 * lane + 2] = rx * fy - ry * fx;
+      yw[3 * lane + 0] = dvy * fz; yw[3 * lane + 1] = -dvx * fz; yw[3 * lane + 2] = dvx * fy - dvy * fx;
+      qq[lane] = p0 * (-rvy * fz) + p1 * (rvx * fz) + p2 * (-rvx * fy + rvy * fx);   // pi . ((R''v) x f), R''v = -Rv
+      if (lane < 3) L(D::oMISC + 9 + lane) = (lane == 0) ? p0 : (lane == 1) ? p1 : p2;
     }
-#ifdef CMPC_NO_DYN_CURV
-    if (lane >= 32 && lane < 35) L(D::oMISC + 9 + lane - 32) = 0.0;
-#else
-    if (lane >= 32 && lane < 35) L(D::oMISC + 9 + lane - 32) = d * L(D::oLAMN + 6 + lane - 32);   // pi
-#endif
     CMPC_SYNC();
-    if (lane < 3) {
-      const int a = lane, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
-      double tau = 0;
-      for (int f = 0; f < 2; ++f) {
-        const double g = L(D::oSR + 17 + f);
-        double fs = 0, t = 0;
-        for (int j = 0; j < NV; ++j) {
-          const int v = f * NV + j;
-          fs += L(D::oUK + 3 * v + a);
-          t += L(D::oVR + 3 * v + a1) * L(D::oUK + 3 * v + a2) - L(D::oVR + 3 * v + a2) * L(D::oUK + 3 * v + a1);
-        }
-        L(D::oMISC + 3 * f + a) = fs;
-        tau += g * t;
+    // (B) sums over the vertices, one lane per result, every lane the same NF independent reads:
+    //   lanes 0..5   Fs[f][a]  = sum_j f_j[a]                         -> MISC 0..5
+    //   lanes 6..8   tau[a]    = sum_f gamma_f sum_j (r_j x f_j)[a]    -> MISC 6..8
+    //   lanes 9..14  Y[f][a]   = sum_j ((R'v_j) x f_j)[a]              -> MISC 21..26
+    //   lanes 15,16  Q[f]      = gamma_f sum_j pi.((R''v_j) x f_j)     -> MISC 30, 31
+    if (lane < 17) {
+      const double gam0 = L(D::oSR + 17), gam1 = L(D::oSR + 18);
+      // role by integer selects only (fsel: -1 both feet, else the foot summed)
+      const int so = (lane < 6) ? D::oUK + lane % 3 : (lane < 9) ? D::oH0 + (lane - 6)
+                   : (lane < 15) ? D::oH0 + 3 * NF + (lane - 9) % 3 : D::oH0 + 6 * NF;
+      const int stride = (lane < 15) ? 3 : 1;
+      const int fsel = (lane < 6) ? lane / 3 : (lane < 9) ? -1 : (lane < 15) ? (lane - 9) / 3 : lane - 15;
+      const bool weighted = (lane >= 6 && lane < 9) || lane >= 15;
+      const int dst = (lane < 9) ? lane : (lane < 15) ? 12 + lane : 15 + lane;
+      const double w0 = weighted ? gam0 : 1.0, w1 = weighted ? gam1 : 1.0;
+      double acc = 0.0;
+#pragma unroll
+      for (int v = 0; v < NF; ++v) {
+        const int f = v / NV;
+        const double val = L(so + v * stride);
+        acc += (fsel < 0 || fsel == f) ? (f ? w1 : w0) * val : 0.0;
       }
-      L(D::oMISC + 6 + a) = tau;
-    }
-    if (lane >= 32 && lane < 34) {           // psi-psi curvature of foot f:  gamma_f sum_j pi . ((R''v_j) x f_j)
-      const int f = lane - 32;
-      const double g = L(D::oSR + 17 + f);
-      const double p0 = L(D::oMISC + 9), p1 = L(D::oMISC + 10), p2 = L(D::oMISC + 11);
-      double acc = 0;
-      for (int j = 0; j < NV; ++j) {
-        const int v = f * NV + j;
-        const double ax = -L(D::oVRV + 3 * v), ay = -L(D::oVRV + 3 * v + 1);
-        const double fx = L(D::oUK + 3 * v), fy = L(D::oUK + 3 * v + 1), fz = L(D::oUK + 3 * v + 2);
-        acc += p0 * (ay * fz) + p1 * (-ax * fz) + p2 * (ax * fy - ay * fx);
-      }
-      L(D::oMISC + 30 + f) = g * acc;
+      L(D::oMISC + dst) = acc;
     }
     CMPC_SYNC();
     // GH[a][col]: rows 6..8 of [B A] minus identity
@@ -390,13 +396,7 @@ template <int NV> struct Solver {
         } else if (s == 12 || s == 16) {     // yaw: d*gamma_f sum_j (R'v_j) x f_j
           const int f = (s == 16);
           const double g = d * L(D::oSR + 17 + f);
-          for (int j = 0; j < NV; ++j) {
-            const int v = f * NV + j;
-            const double ax = L(D::oVDV + 3 * v), ay = L(D::oVDV + 3 * v + 1);
-            const double fx = L(D::oUK + 3 * v), fy = L(D::oUK + 3 * v + 1), fz = L(D::oUK + 3 * v + 2);
-            g0 += ay * fz; g1 += -ax * fz; g2 += ax * fy - ay * fx;
-          }
-          g0 *= g; g1 *= g; g2 *= g;
+          g0 = g * L(D::oMISC + 21 + 3 * f); g1 = g * L(D::oMISC + 22 + 3 * f); g2 = g * L(D::oMISC + 23 + 3 * f);
         }
       }
       L(D::oGH + col) = g0; L(D::oGH + NZ + col) = g1; L(D::oGH + 2 * NZ + col) = g2;
@@ -526,27 +526,37 @@ template <int NV> struct Solver {
   }
 
   // (Jg' w)[col] for row weights w (zero on inactive rows).
-  CMPC_DEV double jgt(int k, int col, const double *w) const {
+  // (Jg' w)[col] for the three weight vectors of a stage at once (multipliers z, sigma*(g+s), 1/s):
+  // the same handful of LDS addresses in each, so one round trip serves all three.
+  CMPC_DEV void jgt3(int k, int col, double (&out)[3]) const {
     const double muf = L(D::oHDR + 21);
-    double v = L(D::oAL + col) * w[R_LYAP];
+    const double *w0 = &L(D::oZK), *w1 = &L(D::oW1), *w2 = &L(D::oW2);
+    const double alc = L(D::oAL + col);
+    double v0 = alc * w0[R_LYAP], v1 = alc * w1[R_LYAP], v2 = alc * w2[R_LYAP];
     if (col < 6 * NV) {
       const int vtx = col / 3, a = col % 3, f = vtx / NV;
       const double gg = (k < N) ? L(D::oSR + 17 + f) : 0.0;
-      const double *wr = w + R_FRIC + 5 * vtx;
-      if (a == 0) v += gg * (wr[0] - wr[1]);
-      else if (a == 1) v += gg * (wr[2] - wr[3]);
-      else v += -gg * muf * (wr[0] + wr[1] + wr[2] + wr[3]) - gg * wr[4];
+      const int b = R_FRIC + 5 * vtx;
+      // all fifteen words of the vertex's friction rows, then the axis picks its combination
+      const double p0 = w0[b], p1 = w0[b + 1], p2 = w0[b + 2], p3 = w0[b + 3], p4 = w0[b + 4];
+      const double q0 = w1[b], q1 = w1[b + 1], q2 = w1[b + 2], q3 = w1[b + 3], q4 = w1[b + 4];
+      const double r0 = w2[b], r1 = w2[b + 1], r2 = w2[b + 2], r3 = w2[b + 3], r4 = w2[b + 4];
+      const double ex = (a == 0) ? gg : 0.0, ey = (a == 1) ? gg : 0.0, ez = (a == 2) ? gg : 0.0;
+      v0 += ex * (p0 - p1) + ey * (p2 - p3) - ez * (muf * ((p0 + p1) + (p2 + p3)) + p4);
+      v1 += ex * (q0 - q1) + ey * (q2 - q3) - ez * (muf * ((q0 + q1) + (q2 + q3)) + q4);
+      v2 += ex * (r0 - r1) + ey * (r2 - r3) - ez * (muf * ((r0 + r1) + (r2 + r3)) + r4);
     } else if (col >= NU) {
       const int s = col - NU;
-      if (s == 2) v += w[R_CZ];
-      else if (s >= 6 && s < 9) v += 2.0 * L(D::oXK + s) * w[R_HWC];
+      if (s == 2) { v0 += w0[R_CZ]; v1 += w1[R_CZ]; v2 += w2[R_CZ]; }
+      else if (s >= 6 && s < 9) { const double xx = 2.0 * L(D::oXK + s); v0 += xx * w0[R_HWC]; v1 += xx * w1[R_HWC]; v2 += xx * w2[R_HWC]; }
       else if ((s >= 13 && s < 16) || (s >= 17 && s < 20)) {
         const int f = (s >= 17), a = (s - 13) % 4;
         const double gg = (k >= 1) ? gam_k(k, f) : 0.0;
-        v += gg * (w[R_BOX + 6 * f + 2 * a] - w[R_BOX + 6 * f + 2 * a + 1]);
+        const int b = R_BOX + 6 * f + 2 * a;
+        v0 += gg * (w0[b] - w0[b + 1]); v1 += gg * (w1[b] - w1[b + 1]); v2 += gg * (w2[b] - w2[b + 1]);
       }
     }
-    return v;
+    out[0] = v0; out[1] = v1; out[2] = v2;
   }
 
   // Objective gradient entry for column col.  reference :275-353
@@ -964,12 +974,29 @@ template <int NV> struct Solver {
           pm[rb][cb][r] = (i < NZ && j <= i) ? M + tri(i) + j : dump;
           old[rb][cb][r] = *pm[rb][cb][r];
         }
+    if constexpr (R0 == NU) {
+      // last block: the trailing matrix is the Schur complement P_k = M_xx - Ls Ls'; it goes straight to
+      // the full symmetric P array (both triangles) that the next stage reads, not back into M
 #pragma unroll
-    for (int rb = 0; rb < NBR; ++rb)
+      for (int rb = 0; rb < NBR; ++rb)
 #pragma unroll
-      for (int cb = 0; cb <= rb; ++cb)
+        for (int cb = 0; cb <= rb; ++cb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *pm[rb][cb][r] = old[rb][cb][r] - acc[rb][cb][r];
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * rb + kq + 4 * r, j = 16 * cb + r16;
+            const bool in = (i < NXA && j <= i);
+            const double v = old[rb][cb][r] - acc[rb][cb][r];
+            *(in ? &L(D::oP + i * D::PS + j) : dump) = v;
+            *(in ? &L(D::oP + j * D::PS + i) : dump) = v;
+          }
+    } else {
+#pragma unroll
+      for (int rb = 0; rb < NBR; ++rb)
+#pragma unroll
+        for (int cb = 0; cb <= rb; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) *pm[rb][cb][r] = old[rb][cb][r] - acc[rb][cb][r];
+    }
     CMPC_SYNC();
     return true;
   }
@@ -986,13 +1013,6 @@ template <int NV> struct Solver {
     if constexpr (NU > 32) { if (!chol_block<32>(M, ok, (NU > 48) || k > 0)) return false; }
     if constexpr (NU > 48) { if (!chol_block<48>(M, ok, k > 0)) return false; }
     CMPC_TICK(8);
-    if (k == 0) return true;
-    for (int e = lane; e < NXA * NXA; e += 64) {
-      const int i = e / NXA, c = e % NXA;
-      const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
-      L(D::oP + i * D::PS + c) = M[tri(NU + hi) + NU + lo];
-    }
-    CMPC_SYNC();
     CMPC_TICK(9);
     return true;
   }
@@ -1114,6 +1134,7 @@ template <int NV> struct Solver {
     for (int k = N; k >= 0; --k) {
       CMPC_OPAQUE(lane);
       load_stage(k, true);
+      CMPC_TICK(24);
       if (k < N) {
         stage_geometry(k);
         if (dbg_on && ka.dbg && k == 5) {   // diagnostic: geometry of stage 5
@@ -1165,11 +1186,7 @@ template <int NV> struct Solver {
         if (col >= NZ) continue;
         const double ho = cost_grad(k, col);
         double jw[3];
-#pragma unroll 1
-        for (int t = 0; t < 3; ++t) {
-          const double v = jgt(k, col, &L((t == 0) ? D::oZK : ((t == 1) ? D::oW1 : D::oW2)));
-          if (t == 0) jw[0] = v; else if (t == 1) jw[1] = v; else jw[2] = v;
-        }
+        jgt3(k, col, jw);
         double r = ho + jw[0];
         if (k < N) for (int n = 0; n < 6; ++n) r += lg[h][n] * L(D::oLAMN + lr[h][n]);
         if (col >= NU) r -= L(D::oLAMK + col - NU);
@@ -1617,7 +1634,7 @@ template <int NV> struct Solver {
     }
 #if defined(CMPC_PROFILE) && !defined(CMPC_HOST_EMU)
     if (lane == 0 && ka.prof)
-      for (int i = 0; i < 24; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);
+      for (int i = 0; i < 28; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);
 #endif
     CMPC_SYNC();
   }

@@ -68,8 +68,8 @@ if os.environ.get("CMPC_PROF"):
     capi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcmpc_amd_prof.so")
     ps = BatchedCentroidalMPC(spec, device="cuda:0")
     ps.solve(d_rec); torch.cuda.synchronize()
-    buf = (ctypes.c_longlong * 24)()
+    buf = (ctypes.c_longlong * 28)()
     ps._lib.cmpc_profile_read(ps._h, buf)
-    tot = float(sum(buf)); names = ["eval_rest", "build_H", "bwd_m", "bwd_lsolve", "store", "bwd_p", "vec_fwd", "step", "chol", "schur", "GtPG_T", "load+geom", "ineq", "Pb", "GtPG_Mupd", "-", "fwd_load", "fwd_backsub", "fwd_dx", "fwd_lam", "step_len", "chol_panels", "chol_mfma", "-"]
+    tot = float(sum(buf)); names = ["eval_rest", "build_H", "bwd_m", "bwd_lsolve", "store", "bwd_p", "vec_fwd", "step", "chol", "schur", "GtPG_T", "load+geom", "ineq", "Pb", "GtPG_Mupd", "-", "fwd_load", "fwd_backsub", "fwd_dx", "fwd_lam", "step_len", "chol_panels", "chol_mfma", "-", "load_stage", "-", "-", "-"]
     print("phase cycles (sum over instances):", {n: "%.1f%%" % (100 * b / tot) for n, b in zip(names, buf)})
     print("cycles per instance-iteration: %.0f" % (tot / it.sum()))
