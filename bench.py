@@ -9,6 +9,12 @@ instances over 8 GPUs = 8192 per GPU, horizon N = 20, 4 vertices per foot, cold 
 --gpus 8 is exactly config 4 (weak scaling).  Every rank solves its shard with no communication and
 one RCCL all-gather returns the first-stage feedback (x_1, u_0) + status of every instance.
 
+Consecutive steps are independent batches, so they are enqueued on --streams (default 2) alternating
+HIP streams, each with its own solver handle, scratch and output buffers: a launch is a queue of
+instances of very different length (20 iterations typical, max_iter = 100 for the ~1 % that never
+settle), its last stragglers keep a few workgroups busy long after the queue is empty, and the next
+step's workgroups fill the idle CUs in the meantime.  --streams 1 gives the strictly serial number.
+
 The JSON line also carries
   roofline      HBM classification of SURVEY.md 8d: algorithmic bytes B_io = 11 728 B per cold N=20
                 solve x solves per launch / kernel time (HIP events on the launch stream) vs 8 TB/s
@@ -55,8 +61,9 @@ def measured_traffic(workload, batch, N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams (solver handles) the steps alternate over")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="instances per GPU")
     ap.add_argument("--workload", default="randomized", choices=["perturbed", "payload", "randomized"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,15 +97,19 @@ def main():
     spec, rec_all = wl.make_workload(args.workload, B=B_total)
     lo, hi = cdist.shard_bounds(B_total, world, rank)
     rec = torch.from_numpy(rec_all[lo:hi].copy()).to(device)       # resident in HBM before timing
-    solver = BatchedCentroidalMPC(spec, device=device)
-    out = torch.empty((hi - lo, spec.nsol), dtype=torch.float64, device=device)
+    S = max(1, args.streams)
+    solvers = [BatchedCentroidalMPC(spec, device=device) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(S)]
+    outs = [torch.empty((hi - lo, spec.nsol), dtype=torch.float64, device=device) for _ in range(S)]
 
-    def step():
-        XU, status, iters, kkt = solver.solve(rec, out=out)
-        fb = cdist.first_stage_feedback(XU, spec.N, spec.nu)
-        packed = torch.cat((fb, status.to(fb.dtype)[:, None], iters.to(fb.dtype)[:, None]), dim=1)
-        full = cdist.gather_shards(packed, B_total)                # the ONE collective (no-op at N=1)
-        return full, status, iters
+    def step(i):
+        j = i % S
+        with torch.cuda.stream(streams[j]):
+            XU, status, iters, kkt = solvers[j].solve(rec, out=outs[j])
+            fb = cdist.first_stage_feedback(XU, spec.N, spec.nu)
+            packed = torch.cat((fb, status.to(fb.dtype)[:, None], iters.to(fb.dtype)[:, None]), dim=1)
+            full = cdist.gather_shards(packed, B_total)            # the ONE collective (no-op at N=1)
+        return full
 
     def sync():
         torch.cuda.synchronize(device)
@@ -106,16 +117,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
-    kernel_ms = []
+    for i in range(args.warmup):
+        step(i)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full, status, iters = step()
-        kernel_ms.append(solver.last_kernel_ms())                 # HIP events on the launch stream
+    for i in range(args.steps):
+        full = step(i)
     sync()
     elapsed = time.perf_counter() - t0
+    # HIP events around each handle's last launch (on its own launch stream), read after the timed
+    # region so that the query does not serialise the streams
+    kernel_ms = [solvers[j].last_kernel_ms() for j in range(min(S, args.steps))]
     last_ms = float(np.mean(kernel_ms))                           # average launch duration, timed region
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -141,11 +153,12 @@ def main():
                                f"({B_total} total), N={spec.N}, 2 feet x {spec.nv} vertices, cold start",
                    "global_batch": B_total, "horizon": spec.N, "tol": spec.tol, "max_iter": spec.max_iter,
                    "converged_fraction": conv_frac, "mean_iterations": mean_iters,
-                   "parallelism": f"batch-sharded x{world}, final all-gather of (x1,u0,status)"},
+                   "parallelism": f"batch-sharded x{world}, final all-gather of (x1,u0,status); "
+                                  f"steps alternate over {S} HIP stream(s)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                      "traffic_source": traffic[1] if traffic else None,
-                     "kernel": "cmpc_solve_kernel<4>", "kernel_ms": last_ms,
+                     "kernel": "cmpc_solve_kernel<4>", "kernel_ms": last_ms, "concurrent_launches": S,
                      "algorithmic_bytes_per_solve": b_io,
                      "note": "latency/FP64-issue bound in practice (SURVEY 8d): see fp64_tflops",
                      "fp64_tflops_model": flops, "fp64_frac_of_vector_peak": flops / FP64_VECTOR_PEAK_TFLOPS},

@@ -30,9 +30,10 @@ __global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_
   for (;;) {
     if (threadIdx.x == 0) next = atomicAdd(ticket, 1);
     __syncthreads();
-    const int p = next;
+    const int tk = next;
     __syncthreads();
-    if (p >= ka.B) break;                       // every wave reaches this exit
+    if (tk >= ka.B) break;                      // every wave reaches this exit
+    const int p = tk;
     cmpc::Solver<NV> s(ka, lds, slab, ka.recs + (size_t)p * nrec);
     s.solve(ka.warm ? ka.warm + (size_t)p * nsol : nullptr, ka.out + (size_t)p * nsol, ka.status + p,
             ka.iters + p, ka.kkt + p, p == 0);

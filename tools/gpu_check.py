@@ -15,6 +15,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 N = int(sys.argv[3]) if len(sys.argv) > 3 else None
 ncheck = int(sys.argv[4]) if len(sys.argv) > 4 else min(B, 256)
 spec, rec = wl.make_workload(name, B=B, N=N)
+if os.environ.get("CMPC_MAX_ITER"):
+    spec.max_iter = int(os.environ["CMPC_MAX_ITER"])
 solver = BatchedCentroidalMPC(spec, device="cuda:0")
 d_rec = torch.from_numpy(rec).to("cuda:0")
 t0 = time.time()
