@@ -34,7 +34,7 @@ typedef struct cmpc_spec {
   int32_t N;                  /* horizon, params['N'] (:10)                           */
   int32_t nv;                 /* contact vertices per foot: 4 (reference, :55-60) or 8 */
   int32_t max_iter;           /* interior-point iteration cap                         */
-  int32_t reserved;
+  int32_t reserved;           /* must be 0                                            */
   double delta;               /* world_time_step*mpc_rate (:11)                       */
   double g;                   /* params['g'] (:18)                                    */
   double k1, k2;              /* change-of-coordinates gains (:27-31)                 */

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_
     const int p = tk;
     cmpc::Solver<NV> s(ka, lds, slab, ka.recs + (size_t)p * nrec);
     s.solve(ka.warm ? ka.warm + (size_t)p * nsol : nullptr, ka.out + (size_t)p * nsol, ka.status + p,
-            ka.iters + p, ka.kkt + p, p == 0);
+            ka.iters + p, ka.kkt + p);
   }
 }
 
@@ -109,7 +109,6 @@ struct cmpc_handle {
   double *scratch = nullptr;
   int *ticket = nullptr;
   long long *prof = nullptr;
-  double *dbg = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   std::string err;
@@ -180,7 +179,6 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   h->grid = h->num_cu * resident_per_cu(spec->nv);
   h->slab_doubles = slab_doubles(spec);
 #ifdef CMPC_PROFILE
-  (void)hipMalloc(&h->dbg, 65536 * sizeof(double));
   if (hipMalloc(&h->prof, 28 * sizeof(long long)) == hipSuccess) (void)hipMemset(h->prof, 0, 28 * sizeof(long long));
 #endif
   if (hipMalloc(&h->scratch, (size_t)h->grid * h->slab_doubles * sizeof(double)) != hipSuccess ||
@@ -217,7 +215,6 @@ int cmpc_solve_batch(cmpc_handle *h, int32_t B, const double *params, const doub
   ka.status = status; ka.iters = iters; ka.kkt = kkt_res;
   ka.scratch = h->scratch; ka.scratch_stride = h->slab_doubles;
   ka.prof = h->prof;
-  ka.dbg = h->dbg;
   const int grid = B < h->grid ? B : h->grid;
   HIP_TRY(h, hipMemsetAsync(h->ticket, 0, sizeof(int), st));
   HIP_TRY(h, hipEventRecord(h->ev0, st));
@@ -292,11 +289,6 @@ const char *cmpc_last_error(cmpc_handle *h) { return h ? h->err.c_str() : g_err.
 const char *cmpc_version(void) { return "cmpc_amd 0.1 (gfx950)"; }
 
 #ifdef CMPC_PROFILE
-/* diagnostic build only: copy out instance 0's full iterate (x, lam, s, z) */
-int cmpc_debug_read(cmpc_handle *h, double *out, int n) {
-  if (!h || !h->dbg || n > 65536) return 1;
-  return hipMemcpy(out, h->dbg, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess;
-}
 /* diagnostic build only: read and reset the phase cycle sums */
 int cmpc_profile_read(cmpc_handle *h, long long *out8) {
   if (!h || !h->prof) return 1;

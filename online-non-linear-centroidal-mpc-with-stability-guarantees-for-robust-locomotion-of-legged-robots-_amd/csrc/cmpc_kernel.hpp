@@ -28,7 +28,6 @@
 #ifndef CMPC_HOST_EMU
 #include <hip/hip_runtime.h>
 #define CMPC_DEV __device__ __forceinline__
-#define CMPC_DEVN __device__ __noinline__
 #define CMPC_LANE ((int)threadIdx.x)
 // One wavefront per workgroup: LDS operations of a wave execute in issue order, so an LDS hand-off
 // between lanes needs no s_barrier -- only that the compiler neither caches nor reorders LDS
@@ -51,8 +50,6 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 #define CMPC_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 // butterfly exchange for wave-wide reductions
 #define CMPC_XOR(v, m) __shfl_xor((v), (m))
-// keeps the scheduler from hoisting every LDS read of an unrolled phase to its top (live ranges)
-#define CMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // makes a per-lane value opaque to the optimiser: stops loop-invariant code motion from hoisting the
 // hundreds of lane-derived index computations out of the stage / iteration loops (they were kept live
 // across the whole solve and spilled)
@@ -83,7 +80,6 @@ struct KArgs {
   double *scratch;      // [grid][scratch_stride]
   size_t scratch_stride;
   long long *prof;      // [8] phase cycle sums (CMPC_PROFILE builds), else null
-  double *dbg;          // diagnostic dump of instance 0's full iterate (x, lam, s, z), else null
 };
 
 enum { R_LYAP = 0, R_CZ = 1, R_HWC = 2, R_BOX = 3, R_FRIC = 15 };
@@ -230,7 +226,6 @@ template <int NV> struct Solver {
   int lr[NH][6];
   double lg[NH][6];
   long long tprof[28] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-  bool dbg_on = false;
 
   CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
       : ka(a), sp(a.sp), lds(l), gs(g), rec(r), N(a.sp.N), lane(CMPC_LANE) {
@@ -270,7 +265,7 @@ template <int NV> struct Solver {
   // Stage iterates and record rows to LDS.  Every global load is issued unconditionally (clamped
   // indices) before the first LDS write: loads inside lane- or stage-conditional blocks compile to
   // one exposed HBM round trip each (load, s_waitcnt vmcnt(0), ds_write), a dozen per stage.
-  CMPC_DEV void load_stage(int k, bool with_mult) {
+  CMPC_DEV void load_stage(int k) {
     static_assert(NXA <= 64 && NU <= 64, "one lane per state / input component");
     constexpr int NIH = (NI + 63) / 64;
     const bool in = k < N;
@@ -279,9 +274,9 @@ template <int NV> struct Solver {
     const double x0 = gx[(size_t)k * NXA + ix], x1 = gx[(size_t)kn * NXA + ix];
     const double u0 = gu[(size_t)ku * NU + iu], up = gupx[(size_t)ku * NU + iu];
     const double r0 = rec[24 + 19 * ku + ir], r1 = rec[24 + 19 * kp + ir], hd = rec[(lane < 24) ? lane : 0];
-    double l0 = 0.0, l1 = 0.0, sv[NIH], zv[NIH];
-    if (with_mult) {                           // wave-uniform
-      l0 = glam[(size_t)k * NXA + ix]; l1 = glam[(size_t)kn * NXA + ix];
+    double sv[NIH], zv[NIH];
+    const double l0 = glam[(size_t)k * NXA + ix], l1 = glam[(size_t)kn * NXA + ix];
+    {
 #pragma unroll
       for (int h = 0; h < NIH; ++h) {
         const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
@@ -290,10 +285,10 @@ template <int NV> struct Solver {
     }
     if (lane < NXA) {
       L(D::oXK + lane) = x0; L(D::oXN1 + lane) = in ? x1 : 0.0;
-      if (with_mult) { L(D::oLAMK + lane) = l0; L(D::oLAMN + lane) = in ? l1 : 0.0; }
+      L(D::oLAMK + lane) = l0; L(D::oLAMN + lane) = in ? l1 : 0.0;
     }
     if (lane < NU) { L(D::oUK + lane) = in ? u0 : 0.0; L(D::oUPX + lane) = in ? up : 0.0; }
-    if (with_mult) {
+    {
 #pragma unroll
       for (int h = 0; h < NIH; ++h) {
         const int r = lane + 64 * h;
@@ -325,11 +320,7 @@ template <int NV> struct Solver {
       const double px = L(D::oXK + 13 + 4 * f), py = L(D::oXK + 14 + 4 * f), pz = L(D::oXK + 15 + 4 * f);
       const double cx = L(D::oXK + 0), cy = L(D::oXK + 1), cz = L(D::oXK + 2);
       const double fx = L(D::oUK + 3 * lane), fy = L(D::oUK + 3 * lane + 1), fz = L(D::oUK + 3 * lane + 2);
-#ifdef CMPC_NO_DYN_CURV
-      const double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-#else
       const double p0 = d * L(D::oLAMN + 6), p1 = d * L(D::oLAMN + 7), p2 = d * L(D::oLAMN + 8);   // pi
-#endif
       const double cs = cos(yaw), sn = sin(yaw);
       double vx, vy; vert_local(j, vx, vy);
       const double rvx = cs * vx - sn * vy, rvy = sn * vx + cs * vy;
@@ -1133,18 +1124,10 @@ template <int NV> struct Solver {
     er.e_d = er.e_p = er.e_c = er.e_cmu = er.sum_mult = 0.0; er.n_mult = 0;
     for (int k = N; k >= 0; --k) {
       CMPC_OPAQUE(lane);
-      load_stage(k, true);
+      load_stage(k);
       CMPC_TICK(24);
       if (k < N) {
         stage_geometry(k);
-        if (dbg_on && ka.dbg && k == 5) {   // diagnostic: geometry of stage 5
-          double *o = ka.dbg + 60000;
-          for (int e = lane; e < 3 * NF; e += 64) o[e] = L(D::oVR + e);
-          o[24 + lane] = L(D::oMISC + lane);
-          for (int e = lane; e < NXA; e += 64) { o[88 + e] = L(D::oXK + e); o[148 + e] = L(D::oBV + e); o[176 + e] = L(D::oXN1 + e); }
-          for (int e = lane; e < NU; e += 64) o[116 + e] = L(D::oUK + e);
-          for (int e = lane; e < 3 * NZ; e += 64) o[210 + e] = L(D::oGH + e);
-        }
       } else {
         for (int c = lane; c < 3 * NZ; c += 64) L(D::oGH + c) = 0.0;
         if (lane < NXA) L(D::oBV + lane) = 0.0;
@@ -1204,9 +1187,7 @@ template <int NV> struct Solver {
       for (int r = lane; r < NI; r += 64) st[D::gG + r] = L(D::oGK + r);
       CMPC_TICK(0);
       CMPC_OPAQUE(lane);
-#ifndef CMPC_X_NO_BUILDH
       build_H(k, reg);
-#endif
       CMPC_SYNC();
       CMPC_TICK(1);
       if (k < N) {
@@ -1225,14 +1206,10 @@ template <int NV> struct Solver {
         CMPC_SYNC();                            // the T tile of add_GtPG aliases BV and the other stage vectors
         CMPC_TICK(13);
         CMPC_OPAQUE(lane);
-#ifndef CMPC_X_NO_GTPG
         add_GtPG();
-#endif
         CMPC_TICK(15);
         CMPC_OPAQUE(lane);
-#ifndef CMPC_X_NO_FACTOR
         if (!factor_stage(k)) return false;
-#endif
         CMPC_TICK(23);
         backward_vectors(k);
         CMPC_TICK(5);
@@ -1546,15 +1523,12 @@ template <int NV> struct Solver {
   }
 
   // ---------------------------------------------------------------------------------------
-  CMPC_DEV void solve(const double *warm, double *out, int32_t *status, int32_t *iters, double *kkt_out,
-                      bool dump = false) {
+  CMPC_DEV void solve(const double *warm, double *out, int32_t *status, int32_t *iters, double *kkt_out) {
     const double tol = sp.tol;
     const double x0n2 = rec[6] * rec[6] + rec[7] * rec[7] + rec[8] * rec[8];
     double mu = MU_INIT, reg_last = 0.0, kkt = INFINITY;
     int st = CMPC_MAX_ITER, it = 0, n_acc = 0, n_stall = 0, polish = -1;
     bool polish_spent = false;
-    double dbg_ap = 0, dbg_ad = 0, dbg_nreg = 0, dbg_mu = 0;
-    dbg_on = dump;
     initial_point(warm);
     CMPC_TICK_RESET();
     for (it = 0; it <= sp.max_iter; ++it) {
@@ -1565,7 +1539,6 @@ template <int NV> struct Solver {
         CMPC_SYNC();
         if (reg == 0.0) reg = (reg_last == 0.0) ? 1e-4 : fmax(1e-20, reg_last / 3);
         else reg *= (reg_last == 0.0) ? 100.0 : 8.0;
-        dbg_nreg += 1;
         if (reg > 1e20) { fail = true; break; }
       }
       if (fail) { st = CMPC_NUMERICAL; break; }
@@ -1591,20 +1564,12 @@ template <int NV> struct Solver {
       else
         while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
           mu = fmax(tol / 10, fmin(MU_FACTOR * mu, mu * sqrt(mu)));
-#ifndef CMPC_X_NO_VEC
       vector_sweeps(mu);
-#endif
       CMPC_TICK(6);
       double ap, ad;
-#ifndef CMPC_X_NO_STEP
       step_lengths(mu, ap, ad);
-#else
-      ap = ad = 1.0;
-#endif
       CMPC_TICK(20);
       n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
-      dbg_ap = ap; dbg_ad = ad; dbg_mu = mu;
-      if (sp.reserved > 0 && it == sp.reserved - 1) break;   // diagnostic: stop before applying step
       apply_step(mu, ap, ad);
       CMPC_TICK(7);
     }
@@ -1612,26 +1577,6 @@ template <int NV> struct Solver {
     for (int e = lane; e < (N + 1) * CMPC_NX; e += 64) out[e] = gx[(size_t)(e / CMPC_NX) * NXA + (e % CMPC_NX)];
     for (int e = lane; e < N * NU; e += 64) out[(size_t)CMPC_NX * (N + 1) + e] = gu[e];
     if (lane == 0) { *status = st; *iters = it; *kkt_out = kkt; }
-    if (dump && ka.dbg) {
-      double *d = ka.dbg;
-      for (int e = lane; e < (N + 1) * NXA; e += 64) { d[e] = gx[e]; d[(N + 1) * NXA + e] = glam[e]; }
-      d += 2 * (N + 1) * NXA;
-      for (int e = lane; e < (N + 1) * NI; e += 64) { d[e] = gsl[e]; d[(N + 1) * NI + e] = gz[e]; }
-      d += 2 * (N + 1) * NI;
-      if (lane == 0) { d[0] = mu; d[1] = reg_last; d[2] = dbg_ap; d[3] = dbg_ad; d[4] = dbg_nreg; }
-      for (int kk = 15; kk <= 18; ++kk)
-        for (int e = lane; e < NXA * NXA; e += 64) ka.dbg[50000 + (kk - 15) * 1000 + e] = stage(kk)[D::gPK + (e / NXA) * D::PKS + (e % NXA)];
-      d += 8;
-      // per-stage vectors of the last Newton step: h (NZ), b (NXA), l (NU), p (NXA), du (NU), dx (NXA)
-      for (int k = 0; k <= N; ++k) {
-        const double *sk = stage(k);
-        double *o = d + (size_t)k * (NZ + 3 * NXA + 3 * NU);
-        for (int e = lane; e < NU; e += 64) o[NZ + 3 * NXA + 2 * NU + e] = sk[D::gLAM + e * NU + e];
-        for (int e = lane; e < NZ; e += 64) o[e] = sk[D::gH0 + e] + dbg_mu * sk[D::gH1 + e];
-        for (int e = lane; e < NXA; e += 64) { o[NZ + e] = sk[D::gB + e]; o[NZ + NXA + NU + e] = sk[D::gPV + e]; o[NZ + 2 * NXA + 2 * NU + e] = gdx[(size_t)k * NXA + e]; }
-        for (int e = lane; e < NU; e += 64) { o[NZ + NXA + e] = sk[D::gL + e]; o[NZ + 2 * NXA + NU + e] = gdu[(size_t)k * NU + e]; }
-      }
-    }
 #if defined(CMPC_PROFILE) && !defined(CMPC_HOST_EMU)
     if (lane == 0 && ka.prof)
       for (int i = 0; i < 28; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);

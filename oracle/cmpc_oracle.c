@@ -718,7 +718,6 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     }
     n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;   /* no room to move: locally infeasible */
     dbg_ap = ap; dbg_ad = ad;
-    if (sp->reserved > 0 && it == sp->reserved - 1) break;   /* diagnostic: stop before applying the step */
     for (int k = 0; k <= N; ++k) {
       if (k >= 1) for (int i = 0; i < nx; ++i) {
         W->x[(size_t)k * nx + i] += ap * W->dx[(size_t)k * nx + i];

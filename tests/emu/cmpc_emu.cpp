@@ -80,7 +80,7 @@ extern "C" int cmpc_emu_solve_batch(const cmpc_spec *sp, int32_t B, const double
   if (sp->N < 1 || sp->N > CMPC_MAX_N || (sp->nv != 4 && sp->nv != 8)) return 1;
   cmpc::KArgs ka;
   ka.sp = *sp; ka.B = B; ka.recs = recs; ka.warm = warm; ka.out = out;
-  ka.status = status; ka.iters = iters; ka.kkt = kkt; ka.prof = nullptr; ka.dbg = nullptr;
+  ka.status = status; ka.iters = iters; ka.kkt = kkt; ka.prof = nullptr;
   const size_t nd = (sp->nv == 4) ? cmpc::Dims<4>::scratch_doubles(sp->N) : cmpc::Dims<8>::scratch_doubles(sp->N);
   const size_t nl = (sp->nv == 4) ? cmpc::Dims<4>::LDS_DOUBLES : cmpc::Dims<8>::LDS_DOUBLES;
   const double fill = getenv("CMPC_EMU_FILL") ? atof(getenv("CMPC_EMU_FILL")) : 0.0;
