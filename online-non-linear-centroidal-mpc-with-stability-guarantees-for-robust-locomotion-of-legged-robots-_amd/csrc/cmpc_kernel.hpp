@@ -1258,8 +1258,11 @@ template <int NV> struct Solver {
   // wave) holds column r of P_k, so  Ls' dx  and  P dx  are the same instruction stream.  The three
   // dense rows of [B A] (angular momentum) are held one column per lane and reduced by butterflies.
   // ---------------------------------------------------------------------------------------
-  CMPC_DEV void vector_sweeps(double mu) {
-    const double m = rec[20];
+  CMPC_DEV void vector_sweeps(double mu, double &ap, double &ad) {
+    const double m = rec[20], muf = rec[21];
+    constexpr int NIH = (NI + 63) / 64;
+    const double tau = fmax(0.99, 1 - mu);
+    double lap = 1.0, lad = 1.0;
     constexpr bool MERGE = D::W_MERGE;
     const bool isA = lane < NU;
     const int lb = MERGE ? lane - NU : lane;
@@ -1278,7 +1281,18 @@ template <int NV> struct Solver {
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int h = 0; h < NH; ++h) gh[r][h] = st[D::gGH + r * D::GHS + lane + 64 * h];
-      const double gl = rec[24 + 19 * ((k < N) ? k : N - 1) + 17], gr = rec[24 + 19 * ((k < N) ? k : N - 1) + 18];
+      // contact flags of the stage (terminal node: header words 22, 23)
+      const double gl = rec[(k < N) ? 24 + 19 * k + 17 : 22], gr = rec[(k < N) ? 24 + 19 * k + 18 : 23];
+      // slack / multiplier directions of the stage are formed here too (one pass over the stages less)
+      double al[NH], sv[NIH], zv[NIH], gv[NIH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) { const int c = lane + 64 * h; al[h] = st[D::gAL + ((c < NZ) ? c : 0)]; }
+#pragma unroll
+      for (int h = 0; h < NIH; ++h) {
+        const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
+        sv[h] = gsl[(size_t)k * NI + rc]; zv[h] = gz[(size_t)k * NI + rc]; gv[h] = st[D::gG + rc];
+      }
+      const double hw0 = gx[(size_t)k * NXA + 6], hw1 = gx[(size_t)k * NXA + 7], hw2 = gx[(size_t)k * NXA + 8];
       double wa[NXA], wb[MERGE ? 1 : NXA], lam[NU];
       {
         const double *pa = st + D::gLS + ((MERGE || isA) ? lane : 0);
@@ -1319,7 +1333,34 @@ template <int NV> struct Solver {
         } else accB = accA;
       }
       if (hasB && isB) glamn[(size_t)k * NXA + lb] = pv0 + mu * pv1 + accB;
-      if (!hasA) { CMPC_SYNC(); break; }      // the caller reuses the stage vectors
+      auto slack_dirs = [&](double ldot) {     // ds, dz and the fraction-to-the-boundary bounds of stage k
+#pragma unroll
+        for (int h = 0; h < NIH; ++h) {
+          const int r = lane + 64 * h;
+          if (r < NI) {
+            const double sr_ = sv[h], zr = zv[h], gr_ = gv[h];
+            double ds = 0.0, dz = 0.0;
+            if (zr != 0.0) {                   // active rows carry z > 0
+              ds = -(gr_ + sr_) - jg_dot(r, ldot, &L(cur), &L(D::oUK), hw0, hw1, hw2, gl, gr, muf);
+              dz = (mu - sr_ * zr - zr * ds) / sr_;
+              if (ds < 0) lap = fmin(lap, -tau * sr_ / ds);
+              if (dz < 0) lad = fmin(lad, -tau * zr / dz);
+            }
+            gds[(size_t)k * NI + r] = ds; gdz[(size_t)k * NI + r] = dz;
+          }
+        }
+      };
+      if (!hasA) {                             // terminal node: no inputs; Lyapunov row inactive
+        double part = 0.0;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const int c = lane + 64 * h;
+          if (c >= NU && c < NZ) part += al[h] * L(cur + c - NU);
+        }
+        slack_dirs(red_sum(part));
+        CMPC_SYNC();                           // the caller reuses the stage vectors
+        break;
+      }
       double duv;
       {                                        // L' du = -(l + Ls' dx), multipliers by readlane
         double treg = isA ? -(l0v + mu * l1v + accA) : 0.0;
@@ -1333,16 +1374,18 @@ template <int NV> struct Solver {
         if (isA) { gdu[(size_t)k * NU + lane] = duv; L(D::oUK + lane) = duv; }
       }
       // dense rows: s_r = sum_c GH[r][c] z_c, z = (du, dx), one column per lane
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // s3: Lyapunov gradient . (du, dx)
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const int c = lane + 64 * h;
         const bool in = c < NZ;                // the row padding in the slab is never written
         const double z = (c < NU) ? duv : (in ? L(cur + c - NU) : 0.0);
         s0 += in ? gh[0][h] * z : 0.0; s1 += in ? gh[1][h] * z : 0.0; s2 += in ? gh[2][h] * z : 0.0;
+        s3 += in ? al[h] * z : 0.0;
       }
-      s0 = red_sum(s0); s1 = red_sum(s1); s2 = red_sum(s2);
+      s0 = red_sum(s0); s1 = red_sum(s1); s2 = red_sum(s2); s3 = red_sum(s3);
       CMPC_SYNC();
+      slack_dirs(s3);
       CMPC_TICK(17);
       // dx+ = b + [B A] (du, dx)
       if (lane < NXA) {
@@ -1369,79 +1412,27 @@ template <int NV> struct Solver {
       { const int t = cur; cur = nxt; nxt = t; }
       CMPC_TICK(18);
     }
+    ap = red_min(lap); ad = red_min(lad);
   }
 
-  // (Jg d)[r] for the stage whose x, dx, du, AL are staged in LDS (XK, XN1=dx, UK=du, AL)
-  CMPC_DEV double jg_dot(int k, int r, double lyap_dot) const {
-    const double muf = L(D::oHDR + 21);
-    const double *dx = &L(D::oXN1), *du = &L(D::oUK);
+  // (Jg d)[r] of one stage: dx, du in LDS, hw = x_k[6..8], g0/g1 = the stage's contact flags
+  CMPC_DEV double jg_dot(int r, double lyap_dot, const double *dx, const double *du, double hw0, double hw1, double hw2,
+                         double g0, double g1, double muf) const {
     if (r == R_LYAP) return lyap_dot;
     if (r == R_CZ) return dx[2];
-    if (r == R_HWC) return 2.0 * (L(D::oXK + 6) * dx[6] + L(D::oXK + 7) * dx[7] + L(D::oXK + 8) * dx[8]);
+    if (r == R_HWC) return 2.0 * (hw0 * dx[6] + hw1 * dx[7] + hw2 * dx[8]);
     if (r < R_FRIC) {
       const int q = r - R_BOX, f = q / 6, a = (q % 6) / 2, sgn = (q & 1) ? -1 : 1;
-      return sgn * gam_k(k, f) * dx[13 + 4 * f + a];
+      return sgn * (f ? g1 : g0) * dx[13 + 4 * f + a];
     }
     const int q = r - R_FRIC, v = q / 5, t = q % 5, f = v / NV;
-    const double gg = L(D::oSR + 17 + f);
+    const double gg = f ? g1 : g0;
     const double fx = du[3 * v], fy = du[3 * v + 1], fz = du[3 * v + 2];
     if (t == 0) return gg * (fx - muf * fz);
     if (t == 1) return gg * (-fx - muf * fz);
     if (t == 2) return gg * (fy - muf * fz);
     if (t == 3) return gg * (-fy - muf * fz);
     return -gg * fz;
-  }
-
-  // Slack / multiplier directions and the fraction-to-the-boundary step lengths.
-  CMPC_DEV void step_lengths(double mu, double &ap, double &ad) {
-    constexpr int NIH = (NI + 63) / 64;
-    const double tau = fmax(0.99, 1 - mu);
-    double lap = 1.0, lad = 1.0;
-    const int ix = (lane < NXA) ? lane : 0, iu = (lane < NU) ? lane : 0, ir = (lane < 19) ? lane : 0;
-    for (int k = 0; k <= N; ++k) {
-      CMPC_OPAQUE(lane);
-      const double *st = stage(k);
-      const int ku = (k < N) ? k : N - 1;
-      // one batch of loads per stage (see load_stage)
-      const double x0 = gx[(size_t)k * NXA + ix], dx0 = gdx[(size_t)k * NXA + ix];
-      const double du0 = gdu[(size_t)ku * NU + iu], r0 = rec[24 + 19 * ku + ir];
-      double al[NH], sv[NIH], zv[NIH], gv[NIH];
-#pragma unroll
-      for (int h = 0; h < NH; ++h) { const int c = lane + 64 * h; al[h] = st[D::gAL + ((c < NZ) ? c : 0)]; }
-#pragma unroll
-      for (int h = 0; h < NIH; ++h) {
-        const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
-        sv[h] = gsl[(size_t)k * NI + rc]; zv[h] = gz[(size_t)k * NI + rc]; gv[h] = st[D::gG + rc];
-      }
-      if (lane < NXA) { L(D::oXK + lane) = x0; L(D::oXN1 + lane) = dx0; }
-      if (lane < NU) L(D::oUK + lane) = (k < N) ? du0 : 0.0;
-      if (lane < 19) L(D::oSR + lane) = (k < N) ? r0 : 0.0;
-      CMPC_SYNC();
-      double part = 0.0;
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int c = lane + 64 * h;
-        if (c < NZ) part += al[h] * ((c < NU) ? L(D::oUK + c) : L(D::oXN1 + c - NU));
-      }
-      const double ldot = red_sum(part);
-#pragma unroll
-      for (int h = 0; h < NIH; ++h) {
-        const int r = lane + 64 * h;
-        if (r < NI) {
-          const double s = sv[h], z = zv[h], g = gv[h];
-          double ds = 0.0, dz = 0.0;
-          if (z != 0.0) {                       // active rows carry z > 0
-            ds = -(g + s) - jg_dot(k, r, ldot);
-            dz = (mu - s * z - z * ds) / s;
-            if (ds < 0) lap = fmin(lap, -tau * s / ds);
-            if (dz < 0) lad = fmin(lad, -tau * z / dz);
-          }
-          gds[(size_t)k * NI + r] = ds; gdz[(size_t)k * NI + r] = dz;
-        }
-      }
-      CMPC_SYNC();
-    }
-    ap = red_min(lap); ad = red_min(lad);
   }
 
   CMPC_DEV void apply_step(double mu, double ap, double ad) {
@@ -1564,11 +1555,9 @@ template <int NV> struct Solver {
       else
         while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
           mu = fmax(tol / 10, fmin(MU_FACTOR * mu, mu * sqrt(mu)));
-      vector_sweeps(mu);
-      CMPC_TICK(6);
       double ap, ad;
-      step_lengths(mu, ap, ad);
-      CMPC_TICK(20);
+      vector_sweeps(mu, ap, ad);
+      CMPC_TICK(6);
       n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
       apply_step(mu, ap, ad);
       CMPC_TICK(7);
