@@ -551,34 +551,40 @@ template <int NV> struct Solver {
   }
 
   // Objective gradient entry for column col.  reference :275-353
-  CMPC_DEV double cost_grad(int k, int col) const {
-    const double *x = &L(D::oXK), *u = &L(D::oUK);
+  // Every lane issues the same handful of LDS reads at clamped per-lane indices and combines them with
+  // per-lane coefficients: the column types used to be separate divergent branches, each with its own
+  // exposed LDS round trips (and the exp() of the height weight inside one of them).
+  CMPC_DEV double cost_grad(int k, int col, double wz) const {
+    const bool stage = k < N, is_u = col < NU, is_f = col < 6 * NV;
+    const int s = is_u ? 0 : col - NU;                                   // state index
+    const int vtx = is_f ? col / 3 : ((s >= CMPC_NX) ? s - CMPC_NX : 0), a = is_f ? col % 3 : 0, f = vtx / NV;
+    const bool is_fp = !is_u && s >= CMPC_NX;                             // carried f_z state
+    const bool is_yaw = !is_u && (s == 12 || s == 16), is_pos = !is_u && ((s >= 13 && s < 16) || (s >= 17 && s < 20));
+    const int ff = is_u ? f : (is_fp ? f : ((s >= 16) ? 1 : 0));          // foot of the column
+    // indices of the words this column needs
+    const int iu = is_u ? col : 3 * vtx + 2;                              // u word (own input, or f_z of the vertex)
+    const int ix = is_u ? CMPC_NX + vtx : s;                              // x word (carried f_z, or own state)
+    const int ip = (s < 3) ? s : (is_yaw ? 15 + ff : (is_pos ? 9 + 3 * ff + (s - 13) % 4 : 0));
+    const double u_ = L(D::oUK + iu), upx = L(D::oUPX + (is_u ? col : 0)), x_ = L(D::oXK + ix), pr = L(D::oSRP + ip);
+    const double fsum = L(D::oMISC + 3 * f + a);
+    const double g1 = L(D::oSR + 17 + ff), gm1 = L(D::oSRP + 17 + ff), gN = L(D::oHDR + 22 + ff);
+    const double gk = (k == N) ? gN : g1;                                 // contact flag at node k
     double v = 0.0;
-    if (col < NU) {
-      if (k >= N) return 0.0;
-      v = sp.prox * (u[col] - L(D::oUPX + col));
-      if (col < 6 * NV) {
-        const int vtx = col / 3, a = col % 3, f = vtx / NV;
-        const double g1 = L(D::oSR + 17 + f);
-        const double a_ = g1 * g1 / NV, coef = NV * a_ * a_ - 2 * a_;
-        const double wa = sp.w_force * g1, wb = sp.w_force * (1 - g1);
-        v += wa * (2 * coef * L(D::oMISC + 3 * f + a) + 2 * u[col]) + wb * 2 * u[col];
-        if (a == 2 && k >= 1) v += 2 * sp.w_rate * gam_km1(f) * (u[col] - x[CMPC_NX + vtx]);
+    if (is_u) {
+      if (stage) {
+        v = sp.prox * (u_ - upx);
+        if (is_f) {
+          const double a_ = g1 * g1 / NV, coef = NV * a_ * a_ - 2 * a_;
+          const double wa = sp.w_force * g1, wb = sp.w_force * (1 - g1);
+          v += wa * (2 * coef * fsum + 2 * u_) + wb * 2 * u_;
+          if (a == 2 && k >= 1) v += 2 * sp.w_rate * gm1 * (u_ - x_);
+        }
       }
-    } else {
-      const int s = col - NU;
-      if (k < 1) return 0.0;
-      const double *pr = &L(D::oSRP);
-      if (s < 3) v = 2 * ((s == 2) ? w_cz(k - 1) : sp.w_cxy) * (x[s] - pr[s]);
-      else if (s >= 6 && s < 9) v = (k < N) ? 2 * sp.w_hw * x[s] : 0.0;
-      else if (s == 12 || s == 16) { const int f = (s == 16); const double g = gam_k(k, f); v = 2 * sp.w_foot * g * g * (x[s] - pr[15 + f]); }
-      else if ((s >= 13 && s < 16) || (s >= 17 && s < 20)) {
-        const int f = (s >= 17), a = (s - 13) % 4; const double g = gam_k(k, f);
-        v = 2 * sp.w_foot * g * g * (x[s] - pr[9 + 3 * f + a]);
-      } else if (s >= CMPC_NX && k < N) {
-        const int vtx = s - CMPC_NX, f = vtx / NV;
-        v = -2 * sp.w_rate * gam_km1(f) * (u[3 * vtx + 2] - x[s]);
-      }
+    } else if (k >= 1) {
+      const double wpos = (s < 3) ? 2 * ((s == 2) ? wz : sp.w_cxy) : ((is_yaw || is_pos) ? 2 * sp.w_foot * gk * gk : 0.0);
+      v = wpos * (x_ - pr);
+      if (s >= 6 && s < 9) v = stage ? 2 * sp.w_hw * x_ : 0.0;
+      if (is_fp) v = stage ? -2 * sp.w_rate * gm1 * (u_ - x_) : 0.0;
     }
     return v;
   }
@@ -1161,13 +1167,15 @@ template <int NV> struct Solver {
       if (k < N && lane < NXA) er.e_p = fmax(er.e_p, fabs(L(D::oBV + lane)));
       if (k >= 1 && lane < NXA) { er.sum_mult += fabs(L(D::oLAMK + lane)); er.n_mult += 1; }
       CMPC_SYNC();
+      CMPC_TICK(25);
       build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
       double *st = stage(k);
+      const double wz = w_cz((k >= 1) ? k - 1 : 0);             // height weight of node k (wave-uniform)
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const int col = lane + 64 * h;
         if (col >= NZ) continue;
-        const double ho = cost_grad(k, col);
+        const double ho = cost_grad(k, col, wz);
         double jw[3];
         jgt3(k, col, jw);
         double r = ho + jw[0];
@@ -1179,6 +1187,7 @@ template <int NV> struct Solver {
         L(D::oH1 + col) = jw[2];
         st[D::gAL + col] = L(D::oAL + col);
       }
+      CMPC_TICK(26);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const int c = lane + 64 * h;

@@ -72,6 +72,6 @@ if os.environ.get("CMPC_PROF"):
     ps.solve(d_rec); torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 28)()
     ps._lib.cmpc_profile_read(ps._h, buf)
-    tot = float(sum(buf)); names = ["eval_rest", "build_H", "bwd_m", "bwd_lsolve", "store", "bwd_p", "vec_fwd", "step", "chol", "schur", "GtPG_T", "load+geom", "ineq", "Pb", "GtPG_Mupd", "-", "fwd_load", "fwd_backsub", "fwd_dx", "fwd_lam", "step_len", "chol_panels", "chol_mfma", "-", "load_stage", "-", "-", "-"]
+    tot = float(sum(buf)); names = ["eval_rest", "build_H", "bwd_m", "bwd_lsolve", "store", "bwd_p", "vec_fwd", "step", "chol", "schur", "GtPG_T", "load+geom", "ineq", "Pb", "GtPG_Mupd", "-", "fwd_load", "fwd_backsub", "fwd_dx", "fwd_lam", "-", "chol_panels", "chol_mfma", "-", "load_stage", "eval_weights", "eval_grad", "-"]
     print("phase cycles (sum over instances):", {n: "%.1f%%" % (100 * b / tot) for n, b in zip(names, buf)})
     print("cycles per instance-iteration: %.0f" % (tot / it.sum()))
