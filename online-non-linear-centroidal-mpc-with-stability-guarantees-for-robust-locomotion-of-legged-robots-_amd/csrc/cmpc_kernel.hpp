@@ -90,7 +90,7 @@ constexpr int ACC_ITERS = 8;
 constexpr double STALL_STEP = 1e-7;
 constexpr int STALL_ITERS = 6;
 // Newton iterations at the final barrier value after the tolerance is first met (see the oracle)
-constexpr int POLISH_ITERS = 2;
+constexpr int POLISH_ITERS = 1;
 // barrier schedule (see the oracle)
 constexpr double MU_INIT = 100.0;
 constexpr double MU_FACTOR = 0.1;

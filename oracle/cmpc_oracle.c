@@ -40,9 +40,9 @@
 #define STALL_STEP 1e-7
 #define STALL_ITERS 6
 /* after the tolerance is first met: POLISH_ITERS more Newton iterations at the final barrier value,
- * so that the returned point is the mu = tol/10 central-path point to ~1e-12 whatever path led there
+ * so that the returned point is the mu = tol/10 central-path point to ~1e-11 whatever path led there
  * (directions whose only curvature is the proximal term need this to be reproducible). */
-#define POLISH_ITERS 2
+#define POLISH_ITERS 1
 /* barrier schedule: start value and linear decrease factor (tuned on the synthetic configs: a large
  * start value centres the first iterates; 0.1 -> 100 cut the mean iteration count from 33 to 23) */
 #define MU_INIT 100.0
