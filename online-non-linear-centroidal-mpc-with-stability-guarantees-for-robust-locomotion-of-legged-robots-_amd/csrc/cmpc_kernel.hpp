@@ -248,10 +248,6 @@ template <int NV> struct Solver {
   // contact flag gamma_f at node k and k-1 from the staged records
   CMPC_DEV double gam_k(int k, int f) const { return (k == N) ? L(D::oHDR + 22 + f) : L(D::oSR + 17 + f); }
   CMPC_DEV double gam_km1(int f) const { return L(D::oSRP + 17 + f); }
-  CMPC_DEV double w_cz(int i) const {
-    double half = sp.w_cz_const * 0.5;
-    return (sp.w_cz_const - half) * exp(-(double)i) + half;
-  }
   CMPC_DEV void vert_local(int j, double &vx, double &vy) const {
     const double Lh = sp.foot_length * 0.5, Wh = sp.foot_width * 0.5;
     const double cx[8] = {Lh, Lh, -Lh, -Lh, Lh, 0.0, -Lh, 0.0};
@@ -592,15 +588,15 @@ template <int NV> struct Solver {
   // ---------------------------------------------------------------------------------------
   // Row `lane` of the Lagrangian Hessian + barrier terms into the packed lower triangle M.
   // ---------------------------------------------------------------------------------------
-  CMPC_DEV void build_H(int k, double reg) {
+  CMPC_DEV void build_H(int k, double reg, double wz) {
 #pragma unroll 1
-    for (int h_ = 0; h_ < NH; ++h_) build_H_row(k, reg, lane + 64 * h_);
+    for (int h_ = 0; h_ < NH; ++h_) build_H_row(k, reg, wz, lane + 64 * h_);
   }
   // One pass over the columns, the same instruction stream for every row: the column type (force
   // axis / foot, velocity, state group) is wave-uniform, everything that depends on the row is a
   // per-lane coefficient computed up front, and entries right of the diagonal are redirected to the
   // lane's dump slot instead of being branched around.  No LDS read-modify-write, no zero fill.
-  CMPC_DEV void build_H_row(int k, double reg, const int irow) {
+  CMPC_DEV void build_H_row(int k, double reg, double wz, const int irow) {
     const bool live = irow < NZ;
     const int i = live ? irow : 0;              // idle lanes shadow row 0 and write only to the dump slot
     const int wlim = live ? i : 0;              // columns j < wlim are written
@@ -734,7 +730,7 @@ template <int NV> struct Solver {
       if (stage) { if (!is_force) diag += 0.0; diag += sp.prox; } else diag = reg + 1.0;   // no inputs at the terminal node
     } else {
       if (k >= 1) {
-        if (s < 3) { diag += 2 * ((s == 2) ? w_cz(k - 1) : sp.w_cxy); if (s == 2) diag += sig[R_CZ]; }
+        if (s < 3) { diag += 2 * ((s == 2) ? wz : sp.w_cxy); if (s == 2) diag += sig[R_CZ]; }
         else if (s >= 6 && s < 9) {
           if (stage) diag += 2 * sp.w_hw;
           if (k == 1) diag += 2 * L(D::oZK + R_HWC) + 4 * sig[R_HWC] * x[s] * x[s];
@@ -1128,7 +1124,13 @@ template <int NV> struct Solver {
   // ---------------------------------------------------------------------------------------
   CMPC_DEV bool matrix_sweep(double mu, double reg, double x0n2, Err &er, bool init) {
     er.e_d = er.e_p = er.e_c = er.e_cmu = er.sum_mult = 0.0; er.n_mult = 0;
+    // height weight of node k, w_z[k-1] = (w/2) e^{-(k-1)} + w/2 (reference :301-305): one exp per sweep, then
+    // e^{-(k-1)} by repeated multiplication as k runs down (the library exp is ~1.5 KB of code per use)
+    const double e1 = 2.718281828459045235360287;
+    double ez = exp(-(double)(N - 1));
     for (int k = N; k >= 0; --k) {
+      const double wz = sp.w_cz_const * 0.5 * ez + sp.w_cz_const * 0.5;
+      ez *= e1;
       CMPC_OPAQUE(lane);
       load_stage(k);
       CMPC_TICK(24);
@@ -1170,7 +1172,6 @@ template <int NV> struct Solver {
       CMPC_TICK(25);
       build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
       double *st = stage(k);
-      const double wz = w_cz((k >= 1) ? k - 1 : 0);             // height weight of node k (wave-uniform)
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const int col = lane + 64 * h;
@@ -1196,7 +1197,7 @@ template <int NV> struct Solver {
       for (int r = lane; r < NI; r += 64) st[D::gG + r] = L(D::oGK + r);
       CMPC_TICK(0);
       CMPC_OPAQUE(lane);
-      build_H(k, reg);
+      build_H(k, reg, wz);
       CMPC_SYNC();
       CMPC_TICK(1);
       if (k < N) {
