@@ -96,6 +96,27 @@ def test_batch_composition_does_not_change_results(gpu):
     assert np.array_equal(d, a[100:164])
 
 
+def test_two_handles_on_two_streams_overlap_without_interference(gpu):
+    """bench.py alternates consecutive batches over two solver handles on two HIP streams (the straggler
+    tail of one launch overlaps the next).  Handles share nothing: the overlapped results are bitwise the
+    serial ones."""
+    spec, rec_a = wl.make_workload("randomized", B=2600, N=20)   # > resident grid, so the launches really overlap
+    rec_b = rec_a[::-1].copy()
+    ref_a, st_a, _, _ = _solve(gpu, spec, rec_a)
+    ref_b, st_b, _, _ = _solve(gpu, spec, rec_b)
+    d_a, d_b = (torch.from_numpy(r).to("cuda:0") for r in (rec_a, rec_b))
+    solvers = [gpu(spec, device="cuda:0") for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    outs = []
+    for j, d in enumerate((d_a, d_b)):
+        with torch.cuda.stream(streams[j]):
+            outs.append(solvers[j].solve(d))
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0][0].cpu().numpy(), ref_a) and np.array_equal(outs[0][1].cpu().numpy(), st_a)
+    assert np.array_equal(outs[1][0].cpu().numpy(), ref_b) and np.array_equal(outs[1][1].cpu().numpy(), st_b)
+
+
 def test_warm_start_parity_and_speedup(gpu, oracle):
     spec, rec = wl.make_workload("perturbed", B=64, N=20, scale=0.5)
     cs = oracle_spec(oracle, spec)
