@@ -620,14 +620,12 @@ template <int NV> struct Solver {
     const bool is_force = i < 6 * NV, is_state = i >= NU;
     const int s = i - NU;                       // state index (state rows)
     const int vtx_i = is_force ? i / 3 : 0, a_i = i % 3, f_i = vtx_i / NV;
-    int ti = -1, ai = 0; double sci = 0.0;     // Lyapunov role: 0 c, 1 v, 2 theta, 3 V (force)
-    if (stage) {
-      if (is_force) { ti = 3; ai = a_i; sci = gam[f_i] / m; }
-      else if (is_state && k >= 1) {
-        if (s < 3) { ti = 0; ai = s; sci = 1.0; } else if (s < 6) { ti = 1; ai = s - 3; sci = 1.0; }
-        else if (s >= 9 && s < 12) { ti = 2; ai = s - 9; sci = 1.0; }
-      }
-    }
+    // Lyapunov role: 0 c, 1 v, 2 theta, 3 V (force), -1 none.  Single-value selects on purpose: hipcc has
+    // miscompiled if / else-if chains that assign several variables per branch (compiler note).
+    const int ts = (s < 3) ? 0 : (s < 6) ? 1 : ((s >= 9 && s < 12) ? 2 : -1);
+    const int ti = !stage ? -1 : (is_force ? 3 : ((is_state && k >= 1) ? ts : -1));
+    const int ai = is_force ? a_i : ((s < 3) ? s : (s < 6) ? s - 3 : s - 9);
+    const double sci = is_force ? gam[f_i] / m : 1.0;
     const int tic = (ti >= 0) ? ti : 0;
     const double sA = (ti >= 0) ? sigL * al[i] : 0.0;
     const double hV = (ti >= 0) ? zL * hq(tic, 3) * sci / m : 0.0;       // against a force column of the same axis
