@@ -900,18 +900,32 @@ template <int NV> struct Solver {
         blk[h][4 * p] = l0; blk[h][4 * p + 1] = l1; blk[h][4 * p + 2] = l2; blk[h][4 * p + 3] = l3;
       }
       if (!ok) return false;                   // pivots are wave-uniform
-      // right-looking inside the block: the remaining block columns of every row
+      // right-looking inside the block: the remaining block columns of every row.  The multipliers of
+      // the block's later rows are handed over through a small LDS table (the T tile is dead here) and
+      // read back at wave-uniform addresses: one ds_read per pair of doubles on the LDS port instead of
+      // four v_readlane on the vector ALU, which is what this phase is bound by.
+      if (4 * p + 4 < W) {
+        double *ub = &L(D::oT);
+        {
+          const int rr = lane - C0;            // row inside the block
+          const bool src = rr >= 4 * p + 4 && rr < W;
+          double *w = src ? ub + 4 * rr : dump;
+          w[0] = blk[0][4 * p];
+          *(src ? w + 1 : dump) = blk[0][4 * p + 1];
+          *(src ? w + 2 : dump) = blk[0][4 * p + 2];
+          *(src ? w + 3 : dump) = blk[0][4 * p + 3];
+        }
+        CMPC_SYNC();
 #pragma unroll
-      for (int cc = 4 * p + 4; cc < W; ++cc) {
-        const int jrow = C0 + cc;              // the row whose multipliers form column cc's update
-        const double u0 = CMPC_BCAST(blk[0][4 * p], jrow), u1 = CMPC_BCAST(blk[0][4 * p + 1], jrow);
-        const double u2 = CMPC_BCAST(blk[0][4 * p + 2], jrow), u3 = CMPC_BCAST(blk[0][4 * p + 3], jrow);
+        for (int cc = 4 * p + 4; cc < W; ++cc) {
+          const double u0 = ub[4 * cc], u1 = ub[4 * cc + 1], u2 = ub[4 * cc + 2], u3 = ub[4 * cc + 3];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          double xv = blk[h][cc];
-          xv = __builtin_fma(-blk[h][4 * p], u0, xv); xv = __builtin_fma(-blk[h][4 * p + 1], u1, xv);
-          xv = __builtin_fma(-blk[h][4 * p + 2], u2, xv); xv = __builtin_fma(-blk[h][4 * p + 3], u3, xv);
-          blk[h][cc] = xv;
+          for (int h = 0; h < NH; ++h) {
+            double xv = blk[h][cc];
+            xv = __builtin_fma(-blk[h][4 * p], u0, xv); xv = __builtin_fma(-blk[h][4 * p + 1], u1, xv);
+            xv = __builtin_fma(-blk[h][4 * p + 2], u2, xv); xv = __builtin_fma(-blk[h][4 * p + 3], u3, xv);
+            blk[h][cc] = xv;
+          }
         }
       }
     }
