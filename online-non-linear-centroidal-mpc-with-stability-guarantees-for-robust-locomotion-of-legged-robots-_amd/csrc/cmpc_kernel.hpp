@@ -1101,22 +1101,37 @@ template <int NV> struct Solver {
         }
       }
       lf0 = m0 * dinv; lf1 = m1 * dinv;
-      if (lane < NU) { st[D::gL + lane] = lf0; st[D::gL1 + lane] = lf1; }
+      if (lane < NU) {
+        st[D::gL + lane] = lf0; st[D::gL1 + lane] = lf1;
+        L(D::oTV + lane) = lf0; L(D::oAL + lane) = lf1;   // handed to the next step at wave-uniform LDS addresses
+      }
     }
+    CMPC_SYNC();
     CMPC_TICK(3);
-    {                                          // p = m_x - Ls l, the entries of l by readlane
+    {                                          // p = m_x - Ls l
       const int lx = (lane < NXA) ? lane : 0;
+      const double *l0 = &L(D::oTV), *l1 = &L(D::oAL);
       double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         double ls[HB];
         if constexpr (HB == 16) lds_read_strided16<1>(ls, M + tri(NU + lx) + hb * HB);
         else lds_read_strided28<1>(ls, M + tri(NU + lx) + hb * HB);
+        if constexpr (HB == 16) {
 #pragma unroll
-        for (int q = 0; q < HB; q += 2) {
-          const int j = hb * HB + q;
-          a0 += ls[q] * CMPC_BCAST(lf0, j); a1 += ls[q + 1] * CMPC_BCAST(lf0, j + 1);
-          b0 += ls[q] * CMPC_BCAST(lf1, j); b1 += ls[q + 1] * CMPC_BCAST(lf1, j + 1);
+          for (int q = 0; q < HB; q += 2) {
+            const int j = hb * HB + q;
+            a0 += ls[q] * l0[j]; a1 += ls[q + 1] * l0[j + 1];
+            b0 += ls[q] * l1[j]; b1 += ls[q + 1] * l1[j + 1];
+          }
+        } else {
+          double v0[HB], v1[HB];
+          lds_read_strided28<1>(v0, l0 + hb * HB); lds_read_strided28<1>(v1, l1 + hb * HB);
+#pragma unroll
+          for (int q = 0; q < HB; q += 2) {
+            a0 += ls[q] * v0[q]; a1 += ls[q + 1] * v0[q + 1];
+            b0 += ls[q] * v1[q]; b1 += ls[q + 1] * v1[q + 1];
+          }
         }
       }
       if (lane < NXA) {
