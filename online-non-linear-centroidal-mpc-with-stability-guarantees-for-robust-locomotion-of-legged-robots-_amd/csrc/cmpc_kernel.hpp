@@ -627,7 +627,8 @@ template <int NV> struct Solver {
     const int ai = is_force ? a_i : ((s < 3) ? s : (s < 6) ? s - 3 : s - 9);
     const double sci = is_force ? gam[f_i] / m : 1.0;
     const int tic = (ti >= 0) ? ti : 0;
-    const double sA = (ti >= 0) ? sigL * al[i] : 0.0;
+    const double al_i = al[i];
+    const double sA = (ti >= 0) ? sigL * al_i : 0.0;
     const double hV = (ti >= 0) ? zL * hq(tic, 3) * sci / m : 0.0;       // against a force column of the same axis
     double zq[3];                                                        // against a c / v / theta column of the same axis
 #pragma unroll
@@ -698,7 +699,6 @@ template <int NV> struct Solver {
         double val = sA * alf[j] + ((a == 0) ? cf0 : (a == 1) ? cf1 : cf2) + gmf * (ccx[a] * dvx + ccy[a] * dvy);
         if (a < 2) val += (j == j_fr0 + a) ? ((a == 0) ? fr0 : fr1) : 0.0;
         if (a == 2) val += (j == j_fp) ? -2 * wr_fp : 0.0;
-        if (j == i) diag += sA * alf[j] + hV * gam[f];                   // Lyapunov part of a force row's diagonal
         *((j < wlim) ? row + j : dump) = val;
       }
     }
@@ -717,13 +717,14 @@ template <int NV> struct Solver {
       double val = 0.0;
       if (tj >= 0) {
         val = sA * als[sj] + ((aj == ai) ? zq[tj] : 0.0);
-        if (j == i) diag += val;
       } else val = hwc_c * x[sj];
       *((j < wlim) ? row + j : dump) = val;
     }
 #pragma unroll 4
     for (int j = NU + 12; j < NZ; ++j) *((j < wlim) ? row + j : dump) = 0.0;
     // ---- diagonal ----
+    // Lyapunov part: the (i, i) entry of the rank-1 term and of the multiplier-weighted constant Hessian
+    if (ti >= 0) diag += sA * al_i + (is_force ? hV * gam[f_i] : ((ti == 0) ? zq[0] : (ti == 1) ? zq[1] : zq[2]));
     if (!is_state) {
       if (stage) { if (!is_force) diag += 0.0; diag += sp.prox; } else diag = reg + 1.0;   // no inputs at the terminal node
     } else {
