@@ -82,3 +82,18 @@ def test_solver_refuses_to_run_without_gpu():
     from cmpc_amd.solver import BatchedCentroidalMPC
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         BatchedCentroidalMPC(ProblemSpec())
+
+
+def test_kernel_isa_has_no_flat_memory_instructions(tmp_path):
+    """LDS must be reached with ds_* instructions only.  A volatile or otherwise opaque access through a
+    generic pointer is emitted as flat_load / flat_store; flat accesses to LDS beyond 64 KB (the 8-vertex
+    kernel allocates 73 KB) raise a GPU memory fault.  Checked on the cross-compiled ISA, no GPU needed."""
+    import subprocess
+    src = os.path.join(_b.PKG, "csrc", "cmpc_hip.hip")
+    out = tmp_path / "kernel.s"
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                           "-o", str(out), src])
+    isa = out.read_text()
+    assert "cmpc_solve_kernel" in isa
+    bad = [ln.strip() for ln in isa.splitlines() if ln.strip().startswith(("flat_load", "flat_store", "flat_atomic"))]
+    assert not bad, bad[:5]
