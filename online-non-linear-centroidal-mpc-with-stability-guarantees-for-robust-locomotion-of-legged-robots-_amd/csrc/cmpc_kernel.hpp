@@ -462,52 +462,52 @@ template <int NV> struct Solver {
       L(D::oRED + a) = -k1 * z1 * z1 - k2 * z2 * z2 + z1 * z2 + z2 * (V - un);
     }
     CMPC_SYNC();
-    // Lyapunov gradient over z = (u, x)
-    for (int col = lane; col < NZ; col += 64) {
-      double v = 0.0;
-      if (k < N) {
-        if (col < 6 * NV) {
-          const int a = col % 3, f = (col / 3) / NV;
-          v = L(D::oSR + 17 + f) / m * (d * L(D::oMISC + 44 + a) + L(D::oMISC + 35 + a));
-        } else if (col >= NU && k >= 1) {
-          const int s = col - NU;
-          if (s < 3) v = L(D::oMISC + 41 + s) + k1 * L(D::oMISC + 44 + s);
-          else if (s < 6) v = d * L(D::oMISC + 41 + s - 3) + (k1 * d + 1) * L(D::oMISC + 44 + s - 3);
-          else if (s >= 9 && s < 12) v = L(D::oMISC + 35 + s - 9) / m;
-        }
-      }
-      L(D::oAL + col) = v;
+    // Lyapunov gradient over z = (u, x): every column is c1 * MISC[i1] + c2 * MISC[i2]; the same two
+    // reads for every lane instead of one divergent path per column type
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int col = lane + 64 * h, cc = (col < NZ) ? col : 0;
+      const bool is_f = cc < 6 * NV, is_x = cc >= NU;
+      const int a = cc % 3, f = (cc / 3) / NV, sx = is_x ? cc - NU : 0;
+      const int grp = (sx < 3) ? 0 : (sx < 6) ? 1 : ((sx >= 9 && sx < 12) ? 2 : 3);   // c, v, theta, none
+      const int ax = (grp == 0) ? sx : (grp == 1) ? sx - 3 : (grp == 2) ? sx - 9 : 0;
+      const int i1 = is_f ? 44 + a : ((grp == 2) ? 35 + ax : 41 + ax), i2 = is_f ? 35 + a : 44 + ax;
+      const double m1 = L(D::oMISC + i1), m2 = L(D::oMISC + i2), gam = L(D::oSR + 17 + (is_f ? f : 0));
+      const double c1 = is_f ? gam * d / m : ((grp == 0) ? 1.0 : (grp == 1) ? d : (grp == 2) ? 1.0 / m : 0.0);
+      const double c2 = is_f ? gam / m : ((grp == 0) ? k1 : (grp == 1) ? k1 * d + 1 : 0.0);
+      const bool on = (k < N) && (is_f || (is_x && k >= 1 && grp < 3));
+      if (col < NZ) L(D::oAL + col) = on ? c1 * m1 + c2 * m2 : 0.0;
     }
-    for (int r = lane; r < NI; r += 64) {
-      double g = 0.0; bool act = false;
-      if (r == R_LYAP) { if (k < N) { g = L(D::oRED) + L(D::oRED + 1) + L(D::oRED + 2) - rl; act = true; } }
-      else if (r == R_CZ) { if (k >= 1 && k < N) { g = L(D::oXK + 2) - sp.cz_max - rl; act = true; } }
-      else if (r == R_HWC) {
-        if (k == 1) { g = L(D::oXK + 6) * L(D::oXK + 6) + L(D::oXK + 7) * L(D::oXK + 7) + L(D::oXK + 8) * L(D::oXK + 8) - x0n2 - rl; act = true; }
-      } else if (r < R_FRIC) {
-        const int q = r - R_BOX, f = q / 6, a = (q % 6) / 2, sgn = (q & 1) ? -1 : 1;
-        if (k >= 1) {
-          const double gg = gam_k(k, f);
-          if (gg != 0.0) {
-            const double dd = (L(D::oXK + 13 + 4 * f + a) - L(D::oSRP + 9 + 3 * f + a)) * gg;
-            g = sgn * dd - sp.box[a] - rl; act = true;
-          }
-        }
-      } else {
-        const int q = r - R_FRIC, v = q / 5, t = q % 5, f = v / NV;
-        if (k < N) {
-          const double gg = L(D::oSR + 17 + f);
-          if (gg != 0.0) {
-            const double fx = L(D::oUK + 3 * v), fy = L(D::oUK + 3 * v + 1), fz = L(D::oUK + 3 * v + 2);
-            double e;
-            if (t == 0) e = fx - muf * fz; else if (t == 1) e = -fx - muf * fz;
-            else if (t == 2) e = fy - muf * fz; else if (t == 3) e = -fy - muf * fz; else e = -fz;
-            g = gg * e - rl; act = true;
-          }
+    // Inequality rows: one batch of clamped reads per lane, the row type picks its combination
+    {
+      constexpr int NIH = (NI + 63) / 64;
+      const double x2 = L(D::oXK + 2), x6 = L(D::oXK + 6), x7 = L(D::oXK + 7), x8 = L(D::oXK + 8);
+      const double red = L(D::oRED) + L(D::oRED + 1) + L(D::oRED + 2);
+#pragma unroll
+      for (int h = 0; h < NIH; ++h) {
+        const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
+        const bool is_box = rc >= R_BOX && rc < R_FRIC, is_fr = rc >= R_FRIC;
+        const int qb = is_box ? rc - R_BOX : 0, fb = qb / 6, ab = (qb % 6) / 2;
+        const int qf = is_fr ? rc - R_FRIC : 0, v = qf / 5, t = qf % 5;
+        const int f = is_box ? fb : v / NV;
+        const double xa = L(D::oXK + 13 + 4 * fb + ab), pa = L(D::oSRP + 9 + 3 * fb + ab);
+        const double gs = L(D::oSR + 17 + f), gN = L(D::oHDR + 22 + f);
+        const double fx = L(D::oUK + 3 * v), fy = L(D::oUK + 3 * v + 1), fz = L(D::oUK + 3 * v + 2);
+        const double gk = (k == N) ? gN : gs;                            // contact flag at node k
+        const double bx = (ab == 0) ? sp.box[0] : (ab == 1) ? sp.box[1] : sp.box[2];
+        const double g_box = ((qb & 1) ? -1.0 : 1.0) * ((xa - pa) * gk) - bx - rl;
+        const double e = (t == 0) ? fx - muf * fz : (t == 1) ? -fx - muf * fz : (t == 2) ? fy - muf * fz
+                       : (t == 3) ? -fy - muf * fz : -fz;
+        const double g_fr = gs * e - rl;
+        const double g_sel = (rc == R_LYAP) ? red - rl : (rc == R_CZ) ? x2 - sp.cz_max - rl
+                           : (rc == R_HWC) ? x6 * x6 + x7 * x7 + x8 * x8 - x0n2 - rl : (is_box ? g_box : g_fr);
+        const bool act = (rc == R_LYAP) ? (k < N) : (rc == R_CZ) ? (k >= 1 && k < N) : (rc == R_HWC) ? (k == 1)
+                       : (is_box ? (k >= 1 && gk != 0.0) : (k < N && gs != 0.0));
+        if (r < NI) {
+          L(D::oGK + r) = act ? g_sel : 0.0;
+          L(D::oW2 + r) = act ? 1.0 : 0.0;     // activity flag (overwritten with 1/s later)
         }
       }
-      L(D::oGK + r) = g;
-      L(D::oW2 + r) = act ? 1.0 : 0.0;     // activity flag (overwritten with 1/s later)
     }
     CMPC_SYNC();
   }
