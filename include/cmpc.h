@@ -51,6 +51,9 @@ typedef struct cmpc_spec {
   double prox;                /* proximal weight on U (build-defined)      */
   double relax;               /* inequality relaxation, IPOPT bound_relax_factor 1e-8 */
   double tol;                 /* scaled KKT tolerance                                 */
+  double acc_tol;             /* acceptable level (CMPC_ACCEPTABLE), default 1e-4: tighter than what the
+                                 reference's IPOPT configuration (tol = 1e-3, :128; constr_viol_tol and
+                                 compl_inf_tol 1e-4 by default) returns as full success              */
 } cmpc_spec;
 
 /* Doubles per instance in the parameter / solution records. */
@@ -61,8 +64,13 @@ typedef struct cmpc_spec {
 /* Per-instance outcome. */
 enum {
   CMPC_CONVERGED = 0,         /* scaled KKT error <= tol                               */
-  CMPC_MAX_ITER = 1,          /* iteration cap reached                                 */
-  CMPC_NUMERICAL = 2          /* regularisation exhausted / non-finite iterate         */
+  CMPC_MAX_ITER = 1,          /* iteration cap reached, error above acc_tol            */
+  CMPC_NUMERICAL = 2,         /* no room to move (locally infeasible: the step length collapsed for several
+                                 iterations), regularisation exhausted or non-finite iterate          */
+  CMPC_INFEASIBLE = 2,        /* the usual meaning of 2: converged to a point of local infeasibility   */
+  CMPC_ACCEPTABLE = 3         /* stopped short of tol with error <= acc_tol (IPOPT's "Solved To Acceptable
+                                 Level", which CasADi's Opti.solve() returns without raising): iteration cap,
+                                 or no progress at the final barrier value                            */
 };
 
 typedef struct cmpc_handle cmpc_handle;

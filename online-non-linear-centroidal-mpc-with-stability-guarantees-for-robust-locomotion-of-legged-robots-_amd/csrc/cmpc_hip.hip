@@ -116,6 +116,18 @@ struct cmpc_handle {
 
 static thread_local std::string g_err;
 
+// Every entry point runs on the handle's device and leaves the caller's current device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+    if (prev == dev) prev = -1;                 // nothing to restore
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 static int fail(cmpc_handle *h, const std::string &msg) {
   if (h) h->err = msg;
   g_err = msg;
@@ -151,6 +163,7 @@ void cmpc_default_spec(cmpc_spec *s, int32_t N, int32_t nv) {
   s->w_hw = 1000.0; s->w_cxy = 1.0; s->w_cz_const = 2000.0; s->w_foot = 1000.0; s->w_force = 10.0;
   s->cz_max = 0.76; s->box[0] = 0.01; s->box[1] = 0.005; s->box[2] = 0.00005;
   s->foot_length = 0.25; s->foot_width = 0.13; s->prox = 1e-4; s->relax = 1e-8; s->tol = 1e-8;
+  s->acc_tol = 1e-4;
 }
 
 size_t cmpc_workspace_bytes(const cmpc_spec *spec, int32_t B) {
@@ -171,7 +184,8 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   cmpc_handle *h = new cmpc_handle();
   h->spec = *spec; h->device = device;
   hipDeviceProp_t prop;
-  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+  DeviceGuard guard(device);
+  if (!guard.ok || hipGetDeviceProperties(&prop, device) != hipSuccess) {
     delete h;
     return fail(nullptr, "cmpc_create: cannot query device");
   }
@@ -193,7 +207,7 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
 
 int cmpc_destroy(cmpc_handle *h) {
   if (!h) return 0;
-  (void)hipSetDevice(h->device);
+  DeviceGuard guard(h->device);
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->ticket) (void)hipFree(h->ticket);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -209,7 +223,8 @@ int cmpc_solve_batch(cmpc_handle *h, int32_t B, const double *params, const doub
   if (B == 0) return 0;
   if (!params || !out_XU || !status || !iters || !kkt_res) return fail(h, "cmpc_solve_batch: null buffer");
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(h, hipSetDevice(h->device));
+  DeviceGuard guard(h->device);
+  if (!guard.ok) return fail(h, "cmpc_solve_batch: cannot select the handle's device");
   cmpc::KArgs ka;
   ka.sp = h->spec; ka.B = B; ka.recs = params; ka.warm = warm_XU; ka.out = out_XU;
   ka.status = status; ka.iters = iters; ka.kkt = kkt_res;
@@ -243,7 +258,8 @@ int cmpc_tables_create(int device, int32_t T, const double *com_tab, const doubl
   *out = nullptr;
   if (T <= 0 || !com_tab || !pose_l || !pose_r || !gl || !gr || !cur_l || !cur_r)
     return fail(nullptr, "cmpc_tables_create: bad argument");
-  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "cmpc_tables_create: bad device");
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(nullptr, "cmpc_tables_create: bad device");
   cmpc_tables *tb = new cmpc_tables();
   tb->device = device; tb->T = T;
   struct { double **dst; const double *src; size_t n; } items[] = {
@@ -262,7 +278,7 @@ int cmpc_tables_create(int device, int32_t T, const double *com_tab, const doubl
 
 int cmpc_tables_destroy(cmpc_tables *tb) {
   if (!tb) return 0;
-  (void)hipSetDevice(tb->device);
+  DeviceGuard guard(tb->device);
   double *ptrs[] = {tb->com_tab, tb->pose_l, tb->pose_r, tb->gl, tb->gr, tb->cur_l, tb->cur_r};
   for (double *p : ptrs) if (p) (void)hipFree(p);
   delete tb;
@@ -275,7 +291,8 @@ int cmpc_build_records(const cmpc_tables *tb, int32_t N, int32_t rate, int32_t B
   if (N < 1 || N > CMPC_MAX_N || rate < 1 || B < 0) return fail(nullptr, "cmpc_build_records: bad argument");
   if (B == 0) return 0;
   if (!t || !state || !records) return fail(nullptr, "cmpc_build_records: null buffer");
-  if (hipSetDevice(tb->device) != hipSuccess) return fail(nullptr, "cmpc_build_records: bad device");
+  DeviceGuard guard(tb->device);
+  if (!guard.ok) return fail(nullptr, "cmpc_build_records: bad device");
   const int nrec = CMPC_NREC(N);
   const int blocks = B < 256 * 32 ? B : 256 * 32;      // grid-stride beyond 32 workgroups per CU
   hipLaunchKernelGGL(cmpc_build_records_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tb->T, N, rate,

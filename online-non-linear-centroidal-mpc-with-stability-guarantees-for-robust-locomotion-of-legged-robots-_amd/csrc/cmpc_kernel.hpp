@@ -89,6 +89,9 @@ constexpr double ACC_FACTOR = 100.0;
 constexpr int ACC_ITERS = 8;
 constexpr double STALL_STEP = 1e-7;
 constexpr int STALL_ITERS = 6;
+// no progress at the final barrier value: NOPROG_ITERS iterations without halving the best KKT error seen
+// there; the run then ends as CMPC_ACCEPTABLE as soon as the error is within spec.acc_tol (see the oracle)
+constexpr int NOPROG_ITERS = 12;
 // Newton iterations at the final barrier value after the tolerance is first met (see the oracle)
 constexpr int POLISH_ITERS = 1;
 // barrier schedule (see the oracle)
@@ -1556,8 +1559,10 @@ template <int NV> struct Solver {
     const double tol = sp.tol;
     const double x0n2 = rec[6] * rec[6] + rec[7] * rec[7] + rec[8] * rec[8];
     double mu = MU_INIT, reg_last = 0.0, kkt = INFINITY;
-    int st = CMPC_MAX_ITER, it = 0, n_acc = 0, n_stall = 0, polish = -1;
+    int st = CMPC_MAX_ITER, it = 0, n_acc = 0, n_stall = 0, polish = -1, since_best = 0;
     bool polish_spent = false;
+    double kkt_best = INFINITY;
+    const double acc_tol = fmax(sp.acc_tol, tol);
     initial_point(warm);
     CMPC_TICK_RESET();
     for (it = 0; it <= sp.max_iter; ++it) {
@@ -1582,12 +1587,23 @@ template <int NV> struct Solver {
           polish = POLISH_ITERS; mu = tol / 10;
         } else {
           n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
-          if (n_acc >= ACC_ITERS) { st = CMPC_CONVERGED; break; }
+          if (n_acc >= ACC_ITERS) { st = CMPC_ACCEPTABLE; break; }
+          if (mu <= tol / 10) {                  // at the final barrier value: progress watch
+            if (kkt < 0.5 * kkt_best) { kkt_best = kkt; since_best = 0; } else ++since_best;
+            if (since_best >= NOPROG_ITERS && kkt <= acc_tol) { st = CMPC_ACCEPTABLE; break; }
+          }
         }
       }
       if (polish == 0) { st = CMPC_CONVERGED; break; }
-      if (it == sp.max_iter) { if (polish >= 0) st = CMPC_CONVERGED; break; }
-      if (!(kkt < INFINITY) || n_stall >= STALL_ITERS) { st = CMPC_NUMERICAL; break; }
+      if (it == sp.max_iter) {
+        if (polish >= 0) st = CMPC_CONVERGED;
+        else if (kkt <= acc_tol) st = CMPC_ACCEPTABLE;
+        break;
+      }
+      if (!(kkt < INFINITY) || n_stall >= STALL_ITERS) {
+        st = (kkt <= acc_tol) ? CMPC_ACCEPTABLE : CMPC_NUMERICAL;
+        break;
+      }
       if (reg > 0) reg_last = reg;
       if (polish > 0) --polish;
       else

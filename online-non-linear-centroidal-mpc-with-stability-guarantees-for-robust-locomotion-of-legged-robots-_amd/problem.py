@@ -47,6 +47,7 @@ class ProblemSpec:
     prox: float = 1e-4            # build-defined proximal weight on U
     relax: float = 1e-8           # IPOPT bound_relax_factor
     tol: float = 1e-8             # KKT tolerance of the batched solver
+    acc_tol: float = 1e-4         # acceptable level (status 3); the reference's IPOPT runs tol = 1e-3 (:128)
     max_iter: int = 100
 
     @property
@@ -143,7 +144,7 @@ class CSpec(ctypes.Structure):
                 ("cz_max", ctypes.c_double), ("box", ctypes.c_double * 3),
                 ("foot_length", ctypes.c_double), ("foot_width", ctypes.c_double),
                 ("prox", ctypes.c_double), ("relax", ctypes.c_double),
-                ("tol", ctypes.c_double)]
+                ("tol", ctypes.c_double), ("acc_tol", ctypes.c_double)]
 
 
 def to_cspec(spec):

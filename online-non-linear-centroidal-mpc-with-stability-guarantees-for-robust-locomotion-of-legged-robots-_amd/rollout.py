@@ -12,7 +12,7 @@ The contact-plan write-back (:656-675) mutates a per-robot plan and is only done
 """
 import torch
 
-from .solver import BatchedCentroidalMPC, DeviceRecordBuilder, STATUS_CONVERGED
+from .solver import BatchedCentroidalMPC, DeviceRecordBuilder, usable
 
 
 class BatchedRollout:
@@ -43,7 +43,7 @@ class BatchedRollout:
         sp = self.spec
         rec = self.builder.build(sp, self.t, self.state)
         XU, status, iters, kkt = self.solver.solve(rec, warm=self.warm)
-        ok = (status == STATUS_CONVERGED) & self.alive
+        ok = usable(status) & self.alive
         x1 = XU[:, 20:40]
         u0 = XU[:, 20 * (sp.N + 1):20 * (sp.N + 1) + sp.nu]
         # instances whose solve failed stop moving (the reference raises, :605-614); the rest advance

@@ -11,7 +11,25 @@ import torch
 from . import capi
 from .problem import ProblemSpec, to_cspec
 
-STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_NUMERICAL = 0, 1, 2
+# per-instance outcome (include/cmpc.h): 3 = stopped short of `tol` with a KKT error within `acc_tol`
+# (IPOPT's "Solved To Acceptable Level", which CasADi's Opti.solve() returns without raising)
+STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_ACCEPTABLE = 0, 1, 2, 3
+STATUS_NUMERICAL = STATUS_INFEASIBLE
+
+
+def usable(status):
+    """Boolean mask of the instances whose solution a caller may use: converged or acceptable."""
+    return (status == STATUS_CONVERGED) | (status == STATUS_ACCEPTABLE)
+
+
+def _device_of(device):
+    """torch.device with an explicit index ('cuda' -> the current device)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError("the solver runs on ROCm GPUs only (device must be a cuda device)")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
 
 
 class BatchedCentroidalMPC:
@@ -19,12 +37,11 @@ class BatchedCentroidalMPC:
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedCentroidalMPC needs a ROCm GPU: there is no CPU fallback")
         self.spec = spec
-        self.device = (torch.device("cuda", torch.cuda.current_device()) if device is None
-                       else torch.device(device))
+        self.device = _device_of(device)
         self._lib = capi.load()
         self._cspec = to_cspec(spec)
         h = ctypes.c_void_p()
-        rc = self._lib.cmpc_create(ctypes.byref(self._cspec), self.device.index or 0, ctypes.byref(h))
+        rc = self._lib.cmpc_create(ctypes.byref(self._cspec), self.device.index, ctypes.byref(h))
         if rc != 0:
             raise RuntimeError("cmpc_create failed: " + self._lib.cmpc_last_error(None).decode())
         self._h = h
@@ -53,12 +70,14 @@ class BatchedCentroidalMPC:
         sp = self.spec
         if not (records.is_cuda and records.dtype == torch.float64 and records.is_contiguous()):
             raise ValueError("records must be a contiguous fp64 CUDA tensor")
+        if records.device != self.device:
+            raise ValueError(f"records live on {records.device}, this handle on {self.device}")
         if records.dim() != 2 or records.shape[1] != sp.nrec:
             raise ValueError(f"records must have shape (B, {sp.nrec})")
         B = records.shape[0]
         if warm is not None:
             if not (warm.is_cuda and warm.dtype == torch.float64 and warm.is_contiguous()
-                    and tuple(warm.shape) == (B, sp.nsol)):
+                    and tuple(warm.shape) == (B, sp.nsol) and warm.device == self.device):
                 raise ValueError(f"warm must be a contiguous fp64 CUDA tensor of shape (B, {sp.nsol})")
         if out is None:
             out = torch.empty((B, sp.nsol), dtype=torch.float64, device=records.device)
@@ -94,13 +113,13 @@ class DeviceRecordBuilder:
         import numpy as np
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceRecordBuilder needs a ROCm GPU: there is no CPU fallback")
-        self.device = (torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device))
+        self.device = _device_of(device)
         self._lib = capi.load()
         T = scene.T
         arrs = [np.ascontiguousarray(a[:T], dtype=np.float64) for a in
                 (scene.com_tab, scene.pose_l, scene.pose_r, scene.gl_tab, scene.gr_tab, scene.cur_l, scene.cur_r)]
         h = ctypes.c_void_p()
-        rc = self._lib.cmpc_tables_create(self.device.index or 0, T, *[a.ctypes.data_as(ctypes.c_void_p) for a in arrs],
+        rc = self._lib.cmpc_tables_create(self.device.index, T, *[a.ctypes.data_as(ctypes.c_void_p) for a in arrs],
                                           ctypes.byref(h))
         if rc != 0:
             raise RuntimeError("cmpc_tables_create failed: " + self._lib.cmpc_last_error(None).decode())
@@ -121,6 +140,8 @@ class DeviceRecordBuilder:
         """t (B,) int32 and state (B, 16) fp64 on the GPU -> records (B, nrec) on the GPU."""
         if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
             raise ValueError("t must be a contiguous int32 CUDA tensor")
+        if t.device != self.device or state.device != self.device:
+            raise ValueError(f"t / state must live on {self.device}")
         B = t.shape[0]
         if not (state.is_cuda and state.dtype == torch.float64 and state.is_contiguous()
                 and tuple(state.shape) == (B, 16)):

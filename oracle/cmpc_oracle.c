@@ -37,6 +37,9 @@
 /* termination safeguards (mirrored by the HIP solver) */
 #define ACC_FACTOR 100.0
 #define ACC_ITERS 8
+/* no progress at the final barrier value: NOPROG_ITERS iterations without halving the best KKT error
+ * seen there.  The run then ends as CMPC_ACCEPTABLE as soon as the error is within spec.acc_tol. */
+#define NOPROG_ITERS 12
 #define STALL_STEP 1e-7
 #define STALL_ITERS 6
 /* after the tolerance is first met: POLISH_ITERS more Newton iterations at the final barrier value,
@@ -606,7 +609,9 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     }
   }
   st->status = CMPC_MAX_ITER; st->n_reg = 0;
-  int it, n_acc = 0, n_stall = 0, polish = -1, polish_spent = 0;
+  int it, n_acc = 0, n_stall = 0, polish = -1, polish_spent = 0, since_best = 0;
+  double kkt_best = INFINITY;
+  const double acc_tol = fmax(sp->acc_tol, tol);
   double dbg_ap = 0, dbg_ad = 0;
   double kkt = INFINITY;
   double *xn = (double *)malloc(sizeof(double) * nx);
@@ -658,12 +663,23 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
       } else {
         /* IPOPT-style acceptable level: ACC_ITERS consecutive iterates within ACC_FACTOR*tol */
         n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
-        if (n_acc >= ACC_ITERS) { st->status = CMPC_CONVERGED; break; }
+        if (n_acc >= ACC_ITERS) { st->status = CMPC_ACCEPTABLE; break; }
+        if (mu <= tol / 10) {                      /* at the final barrier value: progress watch */
+          if (kkt < 0.5 * kkt_best) { kkt_best = kkt; since_best = 0; } else ++since_best;
+          if (since_best >= NOPROG_ITERS && kkt <= acc_tol) { st->status = CMPC_ACCEPTABLE; break; }
+        }
       }
     }
     if (polish == 0) { st->status = CMPC_CONVERGED; break; }
-    if (it == sp->max_iter) { if (polish >= 0) st->status = CMPC_CONVERGED; break; }
-    if (!isfinite(kkt) || n_stall >= STALL_ITERS) { st->status = CMPC_NUMERICAL; break; }
+    if (it == sp->max_iter) {
+      if (polish >= 0) st->status = CMPC_CONVERGED;
+      else if (kkt <= acc_tol) st->status = CMPC_ACCEPTABLE;
+      break;
+    }
+    if (!isfinite(kkt) || n_stall >= STALL_ITERS) {
+      st->status = (isfinite(kkt) && kkt <= acc_tol) ? CMPC_ACCEPTABLE : CMPC_NUMERICAL;
+      break;
+    }
     if (polish > 0) --polish;
     else
       while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
@@ -768,6 +784,7 @@ void cmpc_oracle_default_spec(cmpc_spec *s, int32_t N, int32_t nv) {
   s->w_hw = 1000.0; s->w_cxy = 1.0; s->w_cz_const = 2000.0; s->w_foot = 1000.0; s->w_force = 10.0;
   s->cz_max = 0.76; s->box[0] = 0.01; s->box[1] = 0.005; s->box[2] = 0.00005;
   s->foot_length = 0.25; s->foot_width = 0.13; s->prox = 1e-4; s->relax = 1e-8; s->tol = 1e-10;
+  s->acc_tol = 1e-4;
 }
 
 int cmpc_oracle_solve(const cmpc_spec *sp, const double *rec, const double *warm, double *out,

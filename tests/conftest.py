@@ -32,7 +32,7 @@ def oracle():
 
 def oracle_spec(ol, spec, **over):
     kw = dict(N=spec.N, nv=spec.nv, tol=spec.tol, max_iter=spec.max_iter, k1=spec.k1, k2=spec.k2,
-              prox=spec.prox, w_rate=spec.w_rate, relax=spec.relax, delta=spec.delta)
+              prox=spec.prox, w_rate=spec.w_rate, relax=spec.relax, delta=spec.delta, acc_tol=spec.acc_tol)
     kw.update(over)
     return ol.default_spec(**kw)
 

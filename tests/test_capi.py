@@ -45,7 +45,7 @@ def test_default_spec_and_struct_layout(lib):
             assert list(a) == list(b)
         else:
             assert a == b, name
-    assert ctypes.sizeof(CSpec) == 4 * 4 + 19 * 8            # 4 int32 + 19 doubles, no padding surprises
+    assert ctypes.sizeof(CSpec) == 4 * 4 + 20 * 8            # 4 int32 + 20 doubles, no padding surprises
     assert lib.cmpc_version().decode().startswith("cmpc_amd")
 
 

@@ -44,7 +44,7 @@ def test_parity_with_oracle(gpu, oracle, name, B, N):
         spec.max_iter = 150                                   # long horizons take more iterations
     got, st, it, kkt = _solve(gpu, spec, rec)
     ref, st_ref, it_ref, _ = oracle.solve_batch(oracle_spec(oracle, spec), rec)
-    both = (st == 0) & (st_ref == 0)
+    both = np.isin(st, (0, 3)) & np.isin(st_ref, (0, 3))
     assert (st != st_ref).sum() <= max(2, (0.03 if N <= 20 else 0.15) * B)   # same verdict on (nearly) every instance
     assert both.mean() >= 0.85
     err = rel_inf(got[both], ref[both])
@@ -64,7 +64,7 @@ def test_golden_vectors(gpu, path):
     spec = ProblemSpec(N=int(kat["N"]), nv=int(kat["nv"]), k1=float(kat["k1"]), k2=float(kat["k2"]),
                        tol=1e-10, max_iter=300)
     got, st, it, kkt = _solve(gpu, spec, kat["records"])
-    assert (st == 0).all()
+    assert np.isin(st, (0, 3)).all() and kkt.max() <= 1e-8
     assert rel_inf(got, kat["solutions"]).max() < 1e-5
 
 
@@ -75,7 +75,7 @@ def test_edge_cases_empty_single_and_ragged_batches(gpu, oracle):
     assert got0[0].shape == (0, spec.nsol) and got0[1].shape == (0,)
     for B in (1, 2, 63, 65, 67):                             # around the wavefront width
         got, st, _, _ = _solve(gpu, spec, rec[:B])
-        ok = (st == 0) & (st_ref[:B] == 0)
+        ok = np.isin(st, (0, 3)) & np.isin(st_ref[:B], (0, 3))
         err = rel_inf(got[ok], ref[:B][ok])
         # north-star tolerance for every instance; all but the occasional flat-direction instance
         # (curvature = the 1e-4 proximal weight, KKT tolerance 1e-8) agree to rounding level
@@ -123,7 +123,7 @@ def test_warm_start_parity_and_speedup(gpu, oracle):
     cold, st0, it0, _ = oracle.solve_batch(cs, rec)
     got, st, it, _ = _solve(gpu, spec, rec, warm=cold)
     ref, st_ref, it_ref, _ = oracle.solve_batch(cs, rec, warm=cold)
-    both = (st == 0) & (st_ref == 0) & (st0 == 0)
+    both = np.isin(st, (0, 3)) & np.isin(st_ref, (0, 3)) & np.isin(st0, (0, 3))
     assert both.mean() > 0.9
     # re-centred proximal term: curvature along the flat directions is the 1e-4 proximal weight, so with
     # a KKT tolerance of 1e-8 two correct solvers may differ by ~1e-4 there.  Asserted: the bulk agrees to
@@ -144,7 +144,7 @@ def test_full_size_properties_domain_randomised(gpu):
     """BASELINE config 4 shard (65536 / 8 GPUs): properties that need no oracle."""
     spec, rec = wl.make_workload("randomized", B=8192, N=20)
     got, st, it, kkt = _solve(gpu, spec, rec)
-    conv = st == 0
+    conv = np.isin(st, (0, 3))
     assert conv.mean() > 0.9                                 # the rest are reported as max-iter / locally infeasible
     assert np.isfinite(got).all()
     r = nlp_batch.residuals(spec, rec[conv], got[conv])
@@ -154,7 +154,7 @@ def test_full_size_properties_domain_randomised(gpu):
     assert r["height"].max() < 1e-6 and r["box"].max() < 1e-6
     assert r["lyapunov"].max() < 1e-5 and r["contraction"].max() < 1e-6
     assert r["swing_force"].max() < 1e-6                     # feet in the air carry nothing
-    assert kkt[conv].max() <= 100 * spec.tol and it[conv].max() <= spec.max_iter
+    assert kkt[st == 0].max() <= 100 * spec.tol and kkt[st == 3].max() <= spec.acc_tol and it[conv].max() <= spec.max_iter
 
 
 def test_drop_in_class_matches_reference_call_sites(gpu, oracle, scene):
