@@ -1554,14 +1554,21 @@ template <int NV> struct Solver {
     CMPC_SYNC_GLOBAL();
   }
 
+  // X (20 x (N+1)) then U (nu x N), the reference's layout.  Reads the iterate arrays as apply_step /
+  // initial_point left them (both end with a full fence).
+  CMPC_DEV void write_solution(double *out) {
+    for (int e = lane; e < (N + 1) * CMPC_NX; e += 64) out[e] = gx[(size_t)(e / CMPC_NX) * NXA + (e % CMPC_NX)];
+    for (int e = lane; e < N * NU; e += 64) out[(size_t)CMPC_NX * (N + 1) + e] = gu[e];
+  }
+
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void solve(const double *warm, double *out, int32_t *status, int32_t *iters, double *kkt_out) {
     const double tol = sp.tol;
     const double x0n2 = rec[6] * rec[6] + rec[7] * rec[7] + rec[8] * rec[8];
     double mu = MU_INIT, reg_last = 0.0, kkt = INFINITY;
     int st = CMPC_MAX_ITER, it = 0, n_acc = 0, n_stall = 0, polish = -1, since_best = 0;
-    bool polish_spent = false;
-    double kkt_best = INFINITY;
+    bool use_saved = false;
+    double kkt_best = INFINITY, kkt_saved = INFINITY;
     const double acc_tol = fmax(sp.acc_tol, tol);
     initial_point(warm);
     CMPC_TICK_RESET();
@@ -1580,10 +1587,14 @@ template <int NV> struct Solver {
       const double sm = red_sum(er.sum_mult), nm = red_sum((double)er.n_mult);
       const double sd = fmax(100.0, sm / fmax(nm, 1.0)) / 100.0;
       kkt = fmax(fmax(e_d / sd, e_p), e_c / sd);
-      if (polish >= 0 && kkt > ACC_FACTOR * tol) { polish = -1; polish_spent = true; }   // polishing lost ground
+      if (polish >= 0 && kkt > ACC_FACTOR * tol) {
+        // polishing lost ground (the step at the final barrier value needed an inertia correction): the point
+        // that met the tolerance was written to `out` before the polish and is what is returned
+        st = CMPC_CONVERGED; kkt = kkt_saved; use_saved = true; break;
+      }
       if (polish < 0) {
         if (kkt <= tol) {
-          if (polish_spent) { st = CMPC_CONVERGED; break; }
+          write_solution(out); kkt_saved = kkt;
           polish = POLISH_ITERS; mu = tol / 10;
         } else {
           n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
@@ -1616,9 +1627,7 @@ template <int NV> struct Solver {
       apply_step(mu, ap, ad);
       CMPC_TICK(7);
     }
-    // write X (20 x (N+1)) then U (nu x N)
-    for (int e = lane; e < (N + 1) * CMPC_NX; e += 64) out[e] = gx[(size_t)(e / CMPC_NX) * NXA + (e % CMPC_NX)];
-    for (int e = lane; e < N * NU; e += 64) out[(size_t)CMPC_NX * (N + 1) + e] = gu[e];
+    if (!use_saved) write_solution(out);
     if (lane == 0) { *status = st; *iters = it; *kkt_out = kkt; }
 #if defined(CMPC_PROFILE) && !defined(CMPC_HOST_EMU)
     if (lane == 0 && ka.prof)

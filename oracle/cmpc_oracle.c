@@ -587,6 +587,14 @@ static void initial_point(const prob_t *P, work_t *W, const double *warm) {
     for (int j = 0; j < 2 * nv; ++j) W->x[(size_t)k * nx + CMPC_NX + j] = W->u[(size_t)(k - 1) * nu + 3 * j + 2];
 }
 
+/* X (20 x (N+1)) then U (nu x N), the reference's layout */
+static void write_solution(const prob_t *P, const work_t *W, double *out) {
+  const int N = P->N, nx = P->nx, nu = P->nu;
+  for (int k = 0; k <= N; ++k) memcpy(out + (size_t)k * CMPC_NX, W->x + (size_t)k * nx, sizeof(double) * CMPC_NX);
+  for (int k = 0; k < N; ++k)
+    memcpy(out + (size_t)CMPC_NX * (N + 1) + (size_t)k * nu, W->u + (size_t)k * nu, sizeof(double) * nu);
+}
+
 /* One interior-point solve.  out: X then U (reference layout). */
 static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm, double *out,
                       stats_t *st, int verbose, double *full) {
@@ -609,8 +617,8 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     }
   }
   st->status = CMPC_MAX_ITER; st->n_reg = 0;
-  int it, n_acc = 0, n_stall = 0, polish = -1, polish_spent = 0, since_best = 0;
-  double kkt_best = INFINITY;
+  int it, n_acc = 0, n_stall = 0, polish = -1, since_best = 0, use_saved = 0;
+  double kkt_best = INFINITY, kkt_saved = INFINITY;
   const double acc_tol = fmax(sp->acc_tol, tol);
   double dbg_ap = 0, dbg_ad = 0;
   double kkt = INFINITY;
@@ -655,10 +663,14 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     kkt = fmax(fmax(e_d / sd, e_p), e_c / sd);
     if (verbose)
       printf("it %3d f=%.8e d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e\n", it, fobj, e_d / sd, e_p, e_c / sd, mu, reg_last);
-    if (polish >= 0 && kkt > ACC_FACTOR * tol) { polish = -1; polish_spent = 1; }   /* polishing lost ground */
+    if (polish >= 0 && kkt > ACC_FACTOR * tol) {
+      /* polishing lost ground (the step at the final barrier value needed an inertia correction): the
+       * point that met the tolerance was written to `out` before the polish and is what is returned */
+      st->status = CMPC_CONVERGED; kkt = kkt_saved; use_saved = 1; break;
+    }
     if (polish < 0) {
       if (kkt <= tol) {
-        if (polish_spent) { st->status = CMPC_CONVERGED; break; }
+        write_solution(P, W, out); kkt_saved = kkt;
         polish = POLISH_ITERS; mu = tol / 10;
       } else {
         /* IPOPT-style acceptable level: ACC_ITERS consecutive iterates within ACC_FACTOR*tol */
@@ -750,9 +762,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     }
   }
   free(xn);
-  for (int k = 0; k <= N; ++k) memcpy(out + (size_t)k * CMPC_NX, W->x + (size_t)k * nx, sizeof(double) * CMPC_NX);
-  for (int k = 0; k < N; ++k)
-    memcpy(out + (size_t)CMPC_NX * (N + 1) + (size_t)k * nu, W->u + (size_t)k * nu, sizeof(double) * nu);
+  if (!use_saved) write_solution(P, W, out);
   if (full) {   /* x, lam ((N+1) x nx each), s, z ((N+1) x ni each) */
     memcpy(full, W->x, sizeof(double) * (N + 1) * nx); full += (N + 1) * nx;
     memcpy(full, W->lam, sizeof(double) * (N + 1) * nx); full += (N + 1) * nx;

@@ -45,7 +45,9 @@ def test_parity_with_oracle(gpu, oracle, name, B, N):
     got, st, it, kkt = _solve(gpu, spec, rec)
     ref, st_ref, it_ref, _ = oracle.solve_batch(oracle_spec(oracle, spec), rec)
     both = np.isin(st, (0, 3)) & np.isin(st_ref, (0, 3))
-    assert (st != st_ref).sum() <= max(2, (0.03 if N <= 20 else 0.15) * B)   # same verdict on (nearly) every instance
+    # same verdict (usable: converged / acceptable, or not) on (nearly) every instance; whether a slowly
+    # converging instance ends as 0 or as 3 depends on rounding (eight iterates in a row within 1e-6)
+    assert (np.isin(st, (0, 3)) != np.isin(st_ref, (0, 3))).sum() <= max(2, (0.03 if N <= 20 else 0.15) * B)
     assert both.mean() >= 0.85
     err = rel_inf(got[both], ref[both])
     gerr = group_rel_inf(got[both], ref[both], spec.N, spec.nu)
