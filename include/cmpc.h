@@ -124,6 +124,18 @@ int cmpc_tables_destroy(cmpc_tables *tb);
 int cmpc_build_records(const cmpc_tables *tb, int32_t N, int32_t rate, int32_t B, const int32_t *t,
                        const double *state, double *records, void *stream);
 
+/*
+ * Per-instance contact plans (closed-loop rollouts in which every robot rewrites its own plan,
+ * code/centroidal_mpc_vertices.py:656-675).  The foot positions of x0 come from the plan once t >= 200 (:493-509):
+ * slot_l[t] / slot_r[t] (host arrays, T entries, < n_steps) name the plan entry holding the left / right foot at
+ * tick t, -1 = take the nominal table (cur_l / cur_r).  cmpc_build_records_planned then reads
+ *   plan_pos [B][n_steps][3]   device, the 'pos' of every plan entry of every instance
+ * for those words; everything else is cmpc_build_records.  plan_pos == NULL is cmpc_build_records.
+ */
+int cmpc_tables_set_plan_slots(cmpc_tables *tb, int32_t n_steps, const int32_t *slot_l, const int32_t *slot_r);
+int cmpc_build_records_planned(const cmpc_tables *tb, int32_t N, int32_t rate, int32_t B, const int32_t *t,
+                               const double *state, const double *plan_pos, double *records, void *stream);
+
 const char *cmpc_last_error(cmpc_handle *h);
 const char *cmpc_version(void);
 

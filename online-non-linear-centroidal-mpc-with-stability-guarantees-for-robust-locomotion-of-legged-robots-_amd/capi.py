@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libcmpc_amd.so")
 #: every symbol include/cmpc.h declares
 SYMBOLS = ("cmpc_default_spec", "cmpc_create", "cmpc_destroy", "cmpc_workspace_bytes",
            "cmpc_solve_batch", "cmpc_last_kernel_ms", "cmpc_last_error", "cmpc_version",
-           "cmpc_tables_create", "cmpc_tables_destroy", "cmpc_build_records")
+           "cmpc_tables_create", "cmpc_tables_destroy", "cmpc_build_records",
+           "cmpc_tables_set_plan_slots", "cmpc_build_records_planned")
 
 _lib = None
 
@@ -50,6 +51,10 @@ def load():
     lib.cmpc_tables_destroy.restype = ctypes.c_int
     lib.cmpc_build_records.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     lib.cmpc_build_records.restype = ctypes.c_int
+    lib.cmpc_tables_set_plan_slots.argtypes = [vp, i32, vp, vp]
+    lib.cmpc_tables_set_plan_slots.restype = ctypes.c_int
+    lib.cmpc_build_records_planned.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.cmpc_build_records_planned.restype = ctypes.c_int
     lib.cmpc_version.argtypes = []
     lib.cmpc_version.restype = ctypes.c_char_p
     _lib = lib

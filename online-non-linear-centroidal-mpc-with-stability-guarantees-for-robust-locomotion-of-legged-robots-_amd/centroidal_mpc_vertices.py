@@ -51,9 +51,9 @@ class centroidal_mpc:
             'contact_left': footstep_planner.position_contacts_ref['contact_left'],
             'contact_right': footstep_planner.position_contacts_ref['contact_right']}
 
-        self._solver = BatchedCentroidalMPC(self.spec, device=device)
-        self._device = self._solver.device
+        self._solver = self._make_solver(device)
         self._warm = None                       # previous solution (device tensor)
+        self.last_status, self.last_iterations, self.last_kkt = None, 0, float('nan')
         self.x = np.zeros(20)
         self.u = np.zeros(self.spec.nu)
         self.x_collect = np.zeros((20, self.N + 1))
@@ -70,6 +70,22 @@ class centroidal_mpc:
                             'counter': {'val': 0}}
 
     # ------------------------------------------------------------------------------------
+    def _make_solver(self, device):
+        """The HIP solver handle (raises without a ROCm GPU: there is no CPU fallback)."""
+        solver = BatchedCentroidalMPC(self.spec, device=device)
+        self._device = solver.device
+        return solver
+
+    def _solve_record(self, rec):
+        """opt.solve() of the reference (:606) for one parameter record -> (solution (nsol,) numpy, status,
+        iterations, kkt).  Warm start = previous primal solution, unshifted (:630-631)."""
+        d_rec = torch.from_numpy(rec[None, :]).to(self._device)
+        out, status, iters, kkt = self._solver.solve(d_rec, warm=self._warm)
+        st = int(status.item())
+        if st in (STATUS_CONVERGED, STATUS_ACCEPTABLE):
+            self._warm = out                                    # set_initial(U*, X*), unshifted
+        return out[0].cpu().numpy(), st, int(iters.item()), float(kkt.item())
+
     def solve(self, current, t):
         N, nu, nv = self.N, self.spec.nu, self.spec.nv
         rec = build_record(
@@ -80,18 +96,15 @@ class centroidal_mpc:
             mass=self.mass, mu=0.5, first_swing=self.params['first_swing'], rate=self.mpc_rate,
             contacts_ref=self._contacts_ref)
         self.current_state = rec[0:20].copy()
-        d_rec = torch.from_numpy(rec[None, :]).to(self._device)
-        out, status, iters, kkt = self._solver.solve(d_rec, warm=self._warm)
-        st = int(status.item())
-        self.last_status, self.last_iterations, self.last_kkt = st, int(iters.item()), float(kkt.item())
+        self.last_record = rec
+        sol, st, n_it, kkt = self._solve_record(rec)
+        self.last_status, self.last_iterations, self.last_kkt = st, n_it, kkt
         # The reference returns from opt.solve() on IPOPT's Solve_Succeeded AND Solved_To_Acceptable_Level at
         # tol = 1e-3 (:128); status 3 is a KKT error within spec.acc_tol = 1e-4, tighter than either.  Anything
         # else (locally infeasible, iteration cap) is the reference's RuntimeError path (:605-614).
         if st not in (STATUS_CONVERGED, STATUS_ACCEPTABLE):
             raise RuntimeError(f"centroidal MPC solve failed at t={t}: status {st}, "
-                               f"iterations {int(iters.item())}, KKT error {float(kkt.item()):.3e}")
-        self._warm = out                                        # set_initial(U*, X*), unshifted
-        sol = out[0].cpu().numpy()
+                               f"iterations {n_it}, KKT error {kkt:.3e}")
         X = sol[:20 * (N + 1)].reshape(N + 1, 20).T             # opti_state, 20 x (N+1)
         U = sol[20 * (N + 1):].reshape(N, nu).T                 # U, nu x N
         self.x = X[:, 1].copy()
@@ -125,7 +138,7 @@ class centroidal_mpc:
         ms['pos_contact_right']['val'] = self.x[17:20].copy()
         ms['counter']['val'] = 0
         if self.verbose:
-            print(f"time in solve():{t}  iterations {int(iters.item())}  kkt {float(kkt.item()):.2e}")
+            print(f"time in solve():{t}  iterations {n_it}  kkt {kkt:.2e}")
 
         planner = self.footstep_planner
         if self.params['update_contact'] == 'YES':

@@ -48,12 +48,15 @@ __device__ __forceinline__ double cmpc_record_word(int e, int t, int N, int rate
                                                    const double *__restrict__ com_tab, const double *__restrict__ pose_l,
                                                    const double *__restrict__ pose_r, const double *__restrict__ gl,
                                                    const double *__restrict__ gr, const double *__restrict__ cur_l,
-                                                   const double *__restrict__ cur_r) {
+                                                   const double *__restrict__ cur_r, const double *__restrict__ plan_b,
+                                                   int slot_l, int slot_r) {
   if (e < 12) return st16[e];
   if (e == 12) return st16[12];
-  if (e < 16) return cur_l[(size_t)t * 3 + e - 13];
+  // foot positions of x0 (:493-509): the instance's own plan entry once the plan is consulted (t >= 200),
+  // the nominal table before that (slot < 0) or when the batch shares the nominal plan (plan_b == null)
+  if (e < 16) return (plan_b && slot_l >= 0) ? plan_b[3 * slot_l + e - 13] : cur_l[(size_t)t * 3 + e - 13];
   if (e == 16) return st16[13];
-  if (e < 20) return cur_r[(size_t)t * 3 + e - 17];
+  if (e < 20) return (plan_b && slot_r >= 0) ? plan_b[3 * slot_r + e - 17] : cur_r[(size_t)t * 3 + e - 17];
   if (e < 22) return st16[14 + e - 20];
   if (e == 22) return gl[t + N * rate];
   if (e == 23) return gr[t + N * rate];
@@ -72,18 +75,21 @@ __global__ void __launch_bounds__(256) cmpc_build_records_kernel(
     int T, int N, int rate, int B, int nrec, const int *__restrict__ tick, const double *__restrict__ state,
     const double *__restrict__ com_tab, const double *__restrict__ pose_l, const double *__restrict__ pose_r,
     const double *__restrict__ gl, const double *__restrict__ gr, const double *__restrict__ cur_l,
-    const double *__restrict__ cur_r, double *__restrict__ rec) {
+    const double *__restrict__ cur_r, const double *__restrict__ plan_pos, int n_steps,
+    const int *__restrict__ slot_l_tab, const int *__restrict__ slot_r_tab, double *__restrict__ rec) {
   const double nanv = __builtin_nan("");
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const int t = tick[b];
     const bool bad = t < 0 || t + (N + 1) * rate >= T;
     const double *st16 = state + (size_t)b * 16;
+    const double *plan_b = plan_pos ? plan_pos + (size_t)b * n_steps * 3 : nullptr;
+    const int slot_l = (plan_pos && !bad) ? slot_l_tab[t] : -1, slot_r = (plan_pos && !bad) ? slot_r_tab[t] : -1;
     double *out = rec + (size_t)b * nrec;
     const bool aligned = ((nrec & 1) == 0);             // even record length: every pair is 16-byte aligned
     for (int e = 2 * threadIdx.x; e < nrec; e += 2 * blockDim.x) {
-      const double v0 = bad ? nanv : cmpc_record_word(e, t, N, rate, st16, com_tab, pose_l, pose_r, gl, gr, cur_l, cur_r);
+      const double v0 = bad ? nanv : cmpc_record_word(e, t, N, rate, st16, com_tab, pose_l, pose_r, gl, gr, cur_l, cur_r, plan_b, slot_l, slot_r);
       if (e + 1 < nrec) {
-        const double v1 = bad ? nanv : cmpc_record_word(e + 1, t, N, rate, st16, com_tab, pose_l, pose_r, gl, gr, cur_l, cur_r);
+        const double v1 = bad ? nanv : cmpc_record_word(e + 1, t, N, rate, st16, com_tab, pose_l, pose_r, gl, gr, cur_l, cur_r, plan_b, slot_l, slot_r);
         if (aligned) *reinterpret_cast<double2 *>(out + e) = make_double2(v0, v1);
         else { out[e] = v0; out[e + 1] = v1; }
       } else out[e] = v0;
@@ -98,6 +104,8 @@ struct cmpc_tables {
   int T = 0;
   double *com_tab = nullptr, *pose_l = nullptr, *pose_r = nullptr, *gl = nullptr, *gr = nullptr,
          *cur_l = nullptr, *cur_r = nullptr;
+  int n_steps = 0;                                  // per-instance plans: entries per plan
+  int *slot_l = nullptr, *slot_r = nullptr;         // [T] plan entry holding the left / right foot of x0, -1 = nominal table
 };
 
 struct cmpc_handle {
@@ -281,13 +289,36 @@ int cmpc_tables_destroy(cmpc_tables *tb) {
   DeviceGuard guard(tb->device);
   double *ptrs[] = {tb->com_tab, tb->pose_l, tb->pose_r, tb->gl, tb->gr, tb->cur_l, tb->cur_r};
   for (double *p : ptrs) if (p) (void)hipFree(p);
+  if (tb->slot_l) (void)hipFree(tb->slot_l);
+  if (tb->slot_r) (void)hipFree(tb->slot_r);
   delete tb;
+  return 0;
+}
+
+int cmpc_tables_set_plan_slots(cmpc_tables *tb, int32_t n_steps, const int32_t *slot_l, const int32_t *slot_r) {
+  if (!tb || n_steps < 1 || !slot_l || !slot_r) return fail(nullptr, "cmpc_tables_set_plan_slots: bad argument");
+  for (int t = 0; t < tb->T; ++t)
+    if (slot_l[t] >= n_steps || slot_r[t] >= n_steps) return fail(nullptr, "cmpc_tables_set_plan_slots: slot out of range");
+  DeviceGuard guard(tb->device);
+  if (!guard.ok) return fail(nullptr, "cmpc_tables_set_plan_slots: bad device");
+  const size_t bytes = (size_t)tb->T * sizeof(int);
+  if ((!tb->slot_l && hipMalloc(&tb->slot_l, bytes) != hipSuccess) || (!tb->slot_r && hipMalloc(&tb->slot_r, bytes) != hipSuccess) ||
+      hipMemcpy(tb->slot_l, slot_l, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(tb->slot_r, slot_r, bytes, hipMemcpyHostToDevice) != hipSuccess)
+    return fail(nullptr, "cmpc_tables_set_plan_slots: device allocation / upload failed");
+  tb->n_steps = n_steps;
   return 0;
 }
 
 int cmpc_build_records(const cmpc_tables *tb, int32_t N, int32_t rate, int32_t B, const int32_t *t,
                        const double *state, double *records, void *stream) {
+  return cmpc_build_records_planned(tb, N, rate, B, t, state, nullptr, records, stream);
+}
+
+int cmpc_build_records_planned(const cmpc_tables *tb, int32_t N, int32_t rate, int32_t B, const int32_t *t,
+                               const double *state, const double *plan_pos, double *records, void *stream) {
   if (!tb) return fail(nullptr, "cmpc_build_records: null tables");
+  if (plan_pos && (!tb->slot_l || tb->n_steps < 1)) return fail(nullptr, "cmpc_build_records_planned: call cmpc_tables_set_plan_slots first");
   if (N < 1 || N > CMPC_MAX_N || rate < 1 || B < 0) return fail(nullptr, "cmpc_build_records: bad argument");
   if (B == 0) return 0;
   if (!t || !state || !records) return fail(nullptr, "cmpc_build_records: null buffer");
@@ -297,7 +328,7 @@ int cmpc_build_records(const cmpc_tables *tb, int32_t N, int32_t rate, int32_t B
   const int blocks = B < 256 * 32 ? B : 256 * 32;      // grid-stride beyond 32 workgroups per CU
   hipLaunchKernelGGL(cmpc_build_records_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tb->T, N, rate,
                      B, nrec, t, state, tb->com_tab, tb->pose_l, tb->pose_r, tb->gl, tb->gr, tb->cur_l, tb->cur_r,
-                     records);
+                     plan_pos, tb->n_steps, tb->slot_l, tb->slot_r, records);
   if (hipGetLastError() != hipSuccess) return fail(nullptr, "cmpc_build_records: launch failed");
   return 0;
 }

@@ -92,6 +92,9 @@ constexpr int STALL_ITERS = 6;
 // no progress at the final barrier value: NOPROG_ITERS iterations without halving the best KKT error seen
 // there; the run then ends as CMPC_ACCEPTABLE as soon as the error is within spec.acc_tol (see the oracle)
 constexpr int NOPROG_ITERS = 12;
+// smallest pivot accepted by the stage factorisation: max(PIV_MIN, PIV_FRAC * delta) (see the oracle)
+constexpr double PIV_MIN = 1e-8;
+constexpr double PIV_FRAC = 0.1;
 // Newton iterations at the final barrier value after the tolerance is first met (see the oracle)
 constexpr int POLISH_ITERS = 1;
 // barrier schedule (see the oracle)
@@ -228,6 +231,7 @@ template <int NV> struct Solver {
   // per-lane column list of [B A]: rows / coefficients (id, h0, h1, h2, sp1, sp2)
   int lr[NH][6];
   double lg[NH][6];
+  double piv_min = PIV_MIN;  // pivot acceptance threshold of the current sweep
   long long tprof[28] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 
   CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
@@ -833,7 +837,7 @@ template <int NV> struct Solver {
   // P_k = M_xx - Ls Ls' (the Schur complement) without a separate pass.
   // sqrt(p) and 1/sqrt(p) of a pivot by coupled Newton iterations on the hardware estimate: the
   // library sqrt followed by a division is a ~40-instruction dependent chain (special-case scaling
-  // and fix-ups), and there are NU of them per stage on the critical path.  p > 1e-14 here.
+  // and fix-ups), and there are NU of them per stage on the critical path.  p > PIV_MIN here.
   CMPC_DEV static void pivot_sqrt(double p, double &s, double &inv) {
 #ifdef CMPC_HOST_EMU
     s = sqrt(p); inv = 1.0 / s;
@@ -872,25 +876,25 @@ template <int NV> struct Solver {
       {                                        // the panel itself (first row set): pivots and multipliers by readlane
         double a0 = blk[0][4 * p], a1 = blk[0][4 * p + 1], a2 = blk[0][4 * p + 2], a3 = blk[0][4 * p + 3];
         const double p0 = CMPC_BCAST(a0, J);
-        ok = ok && (p0 > 1e-14);
+        ok = ok && (p0 > piv_min);
         double s0; pivot_sqrt(p0, s0, i0);
         const double l0 = (lane == J) ? s0 : a0 * i0;
         t10 = CMPC_BCAST(l0, J + 1);
         a1 -= l0 * t10;
         const double p1 = CMPC_BCAST(a1, J + 1);
-        ok = ok && (p1 > 1e-14);
+        ok = ok && (p1 > piv_min);
         double s1; pivot_sqrt(p1, s1, i1);
         const double l1 = (lane == J + 1) ? s1 : a1 * i1;
         t20 = CMPC_BCAST(l0, J + 2); t21 = CMPC_BCAST(l1, J + 2);
         a2 -= l0 * t20 + l1 * t21;
         const double p2 = CMPC_BCAST(a2, J + 2);
-        ok = ok && (p2 > 1e-14);
+        ok = ok && (p2 > piv_min);
         double s2; pivot_sqrt(p2, s2, i2);
         const double l2 = (lane == J + 2) ? s2 : a2 * i2;
         t30 = CMPC_BCAST(l0, J + 3); t31 = CMPC_BCAST(l1, J + 3); t32 = CMPC_BCAST(l2, J + 3);
         a3 -= l0 * t30 + l1 * t31 + l2 * t32;
         const double p3 = CMPC_BCAST(a3, J + 3);
-        ok = ok && (p3 > 1e-14);
+        ok = ok && (p3 > piv_min);
         double s3; pivot_sqrt(p3, s3, i3);
         const double l3 = (lane == J + 3) ? s3 : a3 * i3;
         blk[0][4 * p] = l0; blk[0][4 * p + 1] = l1; blk[0][4 * p + 2] = l2; blk[0][4 * p + 3] = l3;
@@ -1155,6 +1159,7 @@ template <int NV> struct Solver {
   // ---------------------------------------------------------------------------------------
   CMPC_DEV bool matrix_sweep(double mu, double reg, double x0n2, Err &er, bool init) {
     er.e_d = er.e_p = er.e_c = er.e_cmu = er.sum_mult = 0.0; er.n_mult = 0;
+    piv_min = fmax(PIV_MIN, PIV_FRAC * reg);
     // height weight of node k, w_z[k-1] = (w/2) e^{-(k-1)} + w/2 (reference :301-305): one exp per sweep, then
     // e^{-(k-1)} by repeated multiplication as k runs down (the library exp is ~1.5 KB of code per use)
     const double e1 = 2.718281828459045235360287;

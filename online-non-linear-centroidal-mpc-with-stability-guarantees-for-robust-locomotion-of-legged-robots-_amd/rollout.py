@@ -1,55 +1,104 @@
 """Closed-loop batched rollout: B independent copies of the controller loop, entirely on the GPU.
 
-Per tick (the reference's ``customPreStep``, code/simulation.py:193-212, without DART):
-  1. parameter records from the per-tick tables and the current centroidal state
-     (``DeviceRecordBuilder`` = front half of ``centroidal_mpc.solve``, :482-600);
+Per tick (the reference's ``customPreStep``, code/simulation.py:193-212, without DART; the single-instance
+twin of this loop is ``walk.WalkHarness`` around the drop-in class):
+  1. parameter records from the per-tick tables, the current centroidal state and the instance's OWN contact
+     plan (``DeviceRecordBuilder`` = front half of ``centroidal_mpc.solve``, :482-600);
   2. batched solve, warm-started from the previous tick's solution, unshifted (:630-631);
-  3. back half of ``solve`` (:614-649): theta_hat is carried from x_1 (:485, :644) and the state is
-     advanced to the MPC's own prediction x_1 (a perfect-tracking centroidal model stands in for the
-     simulator + whole-body controller), optionally disturbed by a velocity push.
-The contact-plan write-back (:656-675) mutates a per-robot plan and is only done by the single-instance
-``centroidal_mpc`` class; here all instances share the nominal plan (``update_contact = 'NO'``).
+  3. back half of ``solve`` (:614-683): theta_hat is carried from x_1 (:485, :644); the contact-plan
+     write-back (:656-675) scatters the predicted landing point x_N of the swing foot into the instance's plan
+     (``update_contact = 'YES'``), guarded by the per-instance ``update_contact_flag``; the state is advanced
+     to the MPC's own prediction x_1 (perfect-tracking centroidal model standing in for simulator +
+     whole-body controller), optionally disturbed by a velocity push.  The angular momentum is either the MPC's
+     prediction or an exogenous measured signal ``hw_measured[t] (+ per-instance offset)`` (see walk.py).
+Everything after the solve is index arithmetic and copies in torch (device memory plumbing); the schedule
+(phases, step indices) is shared by the batch, the plan positions are per instance.
 """
+import numpy as np
 import torch
 
 from .solver import BatchedCentroidalMPC, DeviceRecordBuilder, usable
 
 
 class BatchedRollout:
-    def __init__(self, scene, spec, B, device="cuda:0", mass=None, mu=0.5):
-        self.scene, self.spec, self.B = scene, spec, B
-        self.device = torch.device(device)
-        self.solver = BatchedCentroidalMPC(spec, device=self.device)
+    def __init__(self, scene, spec, B, device="cuda:0", mass=None, mu=0.5, update_contact=True,
+                 hw_measured=None, hw_offset=None, rate=1):
+        self.scene, self.spec, self.B, self.rate = scene, spec, B, rate
+        self.solver = BatchedCentroidalMPC(spec, device=device)
+        self.device = self.solver.device
         self.builder = DeviceRecordBuilder(scene, device=self.device)
-        self.state = torch.zeros((B, 16), dtype=torch.float64, device=self.device)
-        self.state[:, 14] = scene.params['mass'] if mass is None else torch.as_tensor(mass, device=self.device)
-        self.state[:, 15] = torch.as_tensor(mu, dtype=torch.float64, device=self.device)
-        self.t = torch.zeros(B, dtype=torch.int32, device=self.device)
+        dev, f64 = self.device, torch.float64
+        self.state = torch.zeros((B, 16), dtype=f64, device=dev)
+        self.state[:, 14] = scene.params['mass'] if mass is None else torch.as_tensor(mass, dtype=f64, device=dev)
+        self.state[:, 15] = torch.as_tensor(mu, dtype=f64, device=dev)
+        self.t = torch.zeros(B, dtype=torch.int32, device=dev)
         self.warm = None
-        self.alive = torch.ones(B, dtype=torch.bool, device=self.device)
+        self.alive = torch.ones(B, dtype=torch.bool, device=dev)
+        # per-instance plans and the shared schedule (:656-675)
+        self.update_contact = update_contact
+        self.plan_pos = torch.from_numpy(scene.plan_pos).to(dev).repeat(B, 1, 1).contiguous()
+        self.flag = torch.zeros(B, dtype=torch.bool, device=dev)             # update_contact_flag
+        self.counter = torch.zeros(B, dtype=torch.bool, device=dev)          # model_state['counter'] of the last tick
+        T, N = scene.T, spec.N
+        end = np.minimum(np.arange(T) + N * rate - 1, T - 1)
+        cond = scene.is_ss & ~scene.is_ss[end]                                # now 'ss', horizon end 'ds'
+        self._cond = torch.from_numpy(cond).to(dev)
+        self._is_ds = torch.from_numpy(~scene.is_ss).to(dev)
+        self._wb_slot = torch.from_numpy(np.minimum(scene.step_idx + 1, scene.plan_pos.shape[0] - 1).astype(np.int64)).to(dev)
+        # support = lfoot -> the swing foot is the right one -> rows 17:20 of x_N, else rows 13:16
+        self._wb_row = torch.from_numpy(np.where(scene.support_is_l, 17, 13).astype(np.int64)).to(dev)
+        self.hw_measured = None if hw_measured is None else torch.as_tensor(np.asarray(hw_measured), dtype=f64, device=dev)
+        self.hw_offset = None if hw_offset is None else torch.as_tensor(np.asarray(hw_offset), dtype=f64, device=dev)
+
+    def _hw_at(self, t):
+        h = self.hw_measured[torch.clamp(t.long(), max=self.hw_measured.shape[0] - 1)]
+        return h if self.hw_offset is None else h + self.hw_offset
 
     def reset(self, t0, com, dcom, hw=None, theta_hat=None):
-        self.t[:] = torch.as_tensor(t0, dtype=torch.int32, device=self.device)
-        self.state[:, 0:3] = torch.as_tensor(com, dtype=torch.float64, device=self.device)
-        self.state[:, 3:6] = torch.as_tensor(dcom, dtype=torch.float64, device=self.device)
-        self.state[:, 6:9] = 0.0 if hw is None else torch.as_tensor(hw, dtype=torch.float64, device=self.device)
-        self.state[:, 9:12] = 0.0 if theta_hat is None else torch.as_tensor(theta_hat, dtype=torch.float64, device=self.device)
+        dev, f64 = self.device, torch.float64
+        self.t[:] = torch.as_tensor(t0, dtype=torch.int32, device=dev)
+        self.state[:, 0:3] = torch.as_tensor(com, dtype=f64, device=dev)
+        self.state[:, 3:6] = torch.as_tensor(dcom, dtype=f64, device=dev)
+        if hw is not None:
+            self.state[:, 6:9] = torch.as_tensor(hw, dtype=f64, device=dev)
+        elif self.hw_measured is not None:
+            self.state[:, 6:9] = self._hw_at(self.t)
+        else:
+            self.state[:, 6:9] = 0.0
+        self.state[:, 9:12] = 0.0 if theta_hat is None else torch.as_tensor(theta_hat, dtype=f64, device=dev)
         self.state[:, 12:14] = 0.0
         self.warm = None
         self.alive[:] = True
+        self.flag[:] = False
+        self.plan_pos = torch.from_numpy(self.scene.plan_pos).to(dev).repeat(self.B, 1, 1).contiguous()
 
     def step(self, push_dv=None):
         """One control tick for every instance.  Returns (x1 (B,20), u0 (B,nu), status (B,))."""
-        sp = self.spec
-        rec = self.builder.build(sp, self.t, self.state)
+        sp, N = self.spec, self.spec.N
+        rec = self.builder.build(sp, self.t, self.state, rate=self.rate,
+                                 plan_pos=self.plan_pos if self.update_contact else None)
         XU, status, iters, kkt = self.solver.solve(rec, warm=self.warm)
         ok = usable(status) & self.alive
         x1 = XU[:, 20:40]
-        u0 = XU[:, 20 * (sp.N + 1):20 * (sp.N + 1) + sp.nu]
+        u0 = XU[:, 20 * (N + 1):20 * (N + 1) + sp.nu]
+        self.last_records, self.last_XU, self.last_status, self.last_iters = rec, XU, status, iters
+        # plan write-back (:656-675), per instance
+        tl = self.t.long()
+        if self.update_contact:
+            fire = self._cond[tl] & ~self.flag & ok
+            rows = self._wb_row[tl]
+            cols = 20 * N + rows[:, None] + torch.arange(3, device=self.device)[None, :]
+            landing = torch.gather(XU, 1, cols)                               # x_collect[17:20 or 13:16, N]
+            b = torch.nonzero(fire, as_tuple=True)[0]
+            self.plan_pos[b, self._wb_slot[tl][b]] = landing[b]
+            self.flag = (self.flag | fire) & ~(self._is_ds[tl] & ok)
+            self.counter = fire
         # instances whose solve failed stop moving (the reference raises, :605-614); the rest advance
         self.alive = ok
         nxt = self.state.clone()
         nxt[:, 0:12] = x1[:, 0:12]
+        if self.hw_measured is not None:
+            nxt[:, 6:9] = self._hw_at(self.t + 1)
         if push_dv is not None:
             nxt[:, 3:6] += torch.as_tensor(push_dv, dtype=torch.float64, device=self.device)
         self.state = torch.where(ok[:, None], nxt, self.state)

@@ -124,6 +124,12 @@ class DeviceRecordBuilder:
         if rc != 0:
             raise RuntimeError("cmpc_tables_create failed: " + self._lib.cmpc_last_error(None).decode())
         self._h, self.T = h, T
+        self.n_steps = int(scene.plan_pos.shape[0])
+        sl, sr = (np.ascontiguousarray(a[:T], dtype=np.int32) for a in (scene.slot_l, scene.slot_r))
+        rc = self._lib.cmpc_tables_set_plan_slots(self._h, self.n_steps, sl.ctypes.data_as(ctypes.c_void_p),
+                                                  sr.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise RuntimeError("cmpc_tables_set_plan_slots failed: " + self._lib.cmpc_last_error(None).decode())
 
     def close(self):
         if getattr(self, "_h", None):
@@ -136,8 +142,9 @@ class DeviceRecordBuilder:
         except Exception:
             pass
 
-    def build(self, spec, t, state, rate=1, out=None):
-        """t (B,) int32 and state (B, 16) fp64 on the GPU -> records (B, nrec) on the GPU."""
+    def build(self, spec, t, state, rate=1, out=None, plan_pos=None):
+        """t (B,) int32 and state (B, 16) fp64 on the GPU -> records (B, nrec) on the GPU.  plan_pos
+        (B, n_steps, 3): per-instance contact plans (the x0 foot positions of :493-509 come from them)."""
         if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
             raise ValueError("t must be a contiguous int32 CUDA tensor")
         if t.device != self.device or state.device != self.device:
@@ -148,9 +155,13 @@ class DeviceRecordBuilder:
             raise ValueError("state must be a contiguous fp64 CUDA tensor of shape (B, 16)")
         if out is None:
             out = torch.empty((B, spec.nrec), dtype=torch.float64, device=t.device)
+        if plan_pos is not None and not (plan_pos.is_cuda and plan_pos.dtype == torch.float64 and plan_pos.is_contiguous()
+                                         and tuple(plan_pos.shape) == (B, self.n_steps, 3) and plan_pos.device == self.device):
+            raise ValueError(f"plan_pos must be a contiguous fp64 tensor of shape (B, {self.n_steps}, 3) on {self.device}")
         stream = torch.cuda.current_stream(t.device).cuda_stream
-        rc = self._lib.cmpc_build_records(self._h, spec.N, rate, B, t.data_ptr(), state.data_ptr(), out.data_ptr(),
-                                          ctypes.c_void_p(stream))
+        rc = self._lib.cmpc_build_records_planned(self._h, spec.N, rate, B, t.data_ptr(), state.data_ptr(),
+                                                  plan_pos.data_ptr() if plan_pos is not None else None,
+                                                  out.data_ptr(), ctypes.c_void_p(stream))
         if rc != 0:
             raise RuntimeError("cmpc_build_records failed: " + self._lib.cmpc_last_error(None).decode())
         return out

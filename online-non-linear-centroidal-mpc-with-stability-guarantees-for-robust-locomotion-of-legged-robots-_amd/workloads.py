@@ -60,13 +60,27 @@ class Scene:
         self.pose_l, self.pose_r = pose_l, pose_r
         gl, gr = np.ones(T), np.ones(T)
         cur_l, cur_r = np.zeros((T, 3)), np.zeros((T, 3))
+        # schedule tables for per-instance plans (rollout.BatchedRollout): plan entries behind the x0 foot
+        # positions (:493-509), phase and step index of every tick, support foot of the step
+        self.slot_l, self.slot_r = np.full(T, -1, np.int32), np.full(T, -1, np.int32)
+        self.is_ss, self.step_idx = np.zeros(T, bool), np.zeros(T, np.int32)
+        self.support_is_l = np.zeros(T, bool)
         for t in range(T):
+            idx = pl.get_step_index_at_time(t)
+            self.step_idx[t] = idx
+            self.support_is_l[t] = pl.plan[idx]['foot_id'] == 'lfoot'
             if pl.get_phase_at_time(t) != 'ds':
-                if pl.plan[pl.get_step_index_at_time(t)]['foot_id'] == 'lfoot':
+                self.is_ss[t] = True
+                if pl.plan[idx]['foot_id'] == 'lfoot':
                     gr[t] = 0.
                 else:
                     gl[t] = 0.
             cur_l[t], cur_r[t] = current_contacts(pl, pose_l[:, 3:6], pose_r[:, 3:6], t, first)
+            if t >= 200:
+                index = pl.get_step_index_at_time(t - 70)
+                a, b = index + (index % 2), index + (index - 1) % 2
+                self.slot_l[t], self.slot_r[t] = (a, b) if first == 'lfoot' else (b, a)
+        self.plan_pos = np.stack([np.asarray(p['pos'], dtype=np.float64) for p in pl.plan])
         self.gl_tab, self.gr_tab, self.cur_l, self.cur_r = gl, gr, cur_l, cur_r
 
     def t_max(self, N, rate=1):
@@ -156,11 +170,15 @@ def make_workload(name, B=None, N=None, scale=1.0):
     return spec, rec
 
 
-def walk_records(spec, ticks):
-    """Config 1 analogue: the nominal flat-ground walk sampled at `ticks` (x0 on the reference)."""
+def walk_records(spec, ticks, hw=None, theta_hat=None):
+    """Config 1 sampled open loop: records of the nominal flat-ground walk at `ticks` (x0 on the CoM
+    reference, measured angular momentum `hw` (len(ticks), 3) -- zero if None, which puts late single support
+    at the edge of feasibility)."""
     sc = scene()
     t = np.asarray(ticks, dtype=np.int64)
     com, dcom = sc.nominal_state(t)
     B = t.shape[0]
-    return sc.build_records(spec, t, com, dcom, np.zeros((B, 3)), np.zeros((B, 3)), np.zeros(B), np.zeros(B),
+    hw = np.zeros((B, 3)) if hw is None else np.asarray(hw, dtype=np.float64)
+    th = np.zeros((B, 3)) if theta_hat is None else np.asarray(theta_hat, dtype=np.float64)
+    return sc.build_records(spec, t, com, dcom, hw, th, np.zeros(B), np.zeros(B),
                             np.full(B, HRP4_MASS), np.full(B, 0.5))

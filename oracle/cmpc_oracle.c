@@ -40,6 +40,9 @@
 /* no progress at the final barrier value: NOPROG_ITERS iterations without halving the best KKT error
  * seen there.  The run then ends as CMPC_ACCEPTABLE as soon as the error is within spec.acc_tol. */
 #define NOPROG_ITERS 12
+/* pivot acceptance of the stage factorisation (see riccati_backward) */
+#define PIV_MIN 1e-8
+#define PIV_FRAC 0.1
 #define STALL_STEP 1e-7
 #define STALL_ITERS 6
 /* after the tolerance is first met: POLISH_ITERS more Newton iterations at the final barrier value,
@@ -446,6 +449,10 @@ static void work_free(work_t *W) {
 static int riccati_backward(const prob_t *P, work_t *W, double reg) {
   const int N = P->N, nx = P->nx, nu = P->nu, nz = P->nz;
   double *M = W->M, *mv = W->m;
+  /* smallest pivot accepted: with a regularisation delta that barely repairs the inertia a pivot can be
+   * ~1e-14 and the step along that direction is garbage of size 1e+14 * residual (there is no line search
+   * to reject it); asking for PIV_FRAC * delta means delta must clear |lambda_min| by that margin */
+  const double piv_min = fmax(PIV_MIN, PIV_FRAC * reg);
   /* terminal */
   {
     const double *H = W->H + (size_t)N * nz * nz, *h = W->h + (size_t)N * nz;
@@ -489,7 +496,7 @@ static int riccati_backward(const prob_t *P, work_t *W, double reg) {
     for (int j = 0; j < nu && rc == 0; ++j) {
       double dsum = M[j * nz + j];
       for (int q = 0; q < j; ++q) dsum -= Lm[j * nu + q] * Lm[j * nu + q];
-      if (!(dsum > 1e-14)) { rc = -1; break; }
+      if (!(dsum > piv_min)) { rc = -1; break; }
       double dj = sqrt(dsum);
       Lm[j * nu + j] = dj;
       for (int i = j + 1; i < nu; ++i) {
