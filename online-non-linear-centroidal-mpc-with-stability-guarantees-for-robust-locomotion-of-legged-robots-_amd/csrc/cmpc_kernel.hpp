@@ -1067,9 +1067,14 @@ template <int NV> struct Solver {
   }
 
   // Backward vector recursion of stage k, run inside the matrix sweep while L and Ls are still in
-  // LDS (packed rows of M).  The barrier value is only known after the whole sweep, but the
-  // recursion is linear in the gradient h = h0 + mu*h1, so both coefficient sets are propagated:
-  //   l = l0 + mu*l1,   p = p0 + mu*p1.
+  // LDS (packed rows of M).  The barrier value of the step is only chosen after the whole sweep, but the
+  // recursion is linear in the gradient h = h(mu_sweep) + (mu - mu_sweep) * h1, so both parts are propagated:
+  //   l = l0 + (mu - mu_sweep) * l1,   p = p0 + (mu - mu_sweep) * p1.
+  // The split is taken AROUND the sweep's barrier value on purpose: near a solution grad f + Jg' (mu/s) is a
+  // difference of O(|z|) terms that cancels to O(KKT error); propagating "h without the barrier term" and
+  // "the barrier term" separately and adding them afterwards leaves a noise floor of eps * |z| * cond on the
+  // step (seen as a dual residual that stops at ~1e-6 or grows).  With this split the correction vanishes
+  // whenever the barrier value is unchanged, which is every iteration of the end game.
   // Entry: XN1 = p0_{k+1} + P_{k+1} b,  PC1 = p1_{k+1},  H0/H1 = gradient parts of this stage.
   CMPC_DEV void backward_vectors(int k) {
     double *st = stage(k);
@@ -1220,7 +1225,7 @@ template <int NV> struct Solver {
         if (col >= NU) r -= L(D::oLAMK + col - NU);
         const bool is_var = (col < NU) ? (k < N) : (k >= 1);
         if (is_var) er.e_d = fmax(er.e_d, fabs(r));
-        L(D::oH0 + col) = ho + jw[1];
+        L(D::oH0 + col) = ho + jw[1] + mu * jw[2];   // gradient at the sweep's barrier value (see backward_vectors)
         L(D::oH1 + col) = jw[2];
         st[D::gAL + col] = L(D::oAL + col);
       }
@@ -1304,7 +1309,7 @@ template <int NV> struct Solver {
   // wave) holds column r of P_k, so  Ls' dx  and  P dx  are the same instruction stream.  The three
   // dense rows of [B A] (angular momentum) are held one column per lane and reduced by butterflies.
   // ---------------------------------------------------------------------------------------
-  CMPC_DEV void vector_sweeps(double mu, double &ap, double &ad) {
+  CMPC_DEV void vector_sweeps(double mu, double dmu, double &ap, double &ad) {
     const double m = rec[20], muf = rec[21];
     constexpr int NIH = (NI + 63) / 64;
     const double tau = fmax(0.99, 1 - mu);
@@ -1378,7 +1383,7 @@ template <int NV> struct Solver {
           accB = (b0 + b1) + (b2 + b3);
         } else accB = accA;
       }
-      if (hasB && isB) glamn[(size_t)k * NXA + lb] = pv0 + mu * pv1 + accB;
+      if (hasB && isB) glamn[(size_t)k * NXA + lb] = pv0 + dmu * pv1 + accB;
       auto slack_dirs = [&](double ldot) {     // ds, dz and the fraction-to-the-boundary bounds of stage k
 #pragma unroll
         for (int h = 0; h < NIH; ++h) {
@@ -1409,7 +1414,7 @@ template <int NV> struct Solver {
       }
       double duv;
       {                                        // L' du = -(l + Ls' dx), multipliers by readlane
-        double treg = isA ? -(l0v + mu * l1v + accA) : 0.0;
+        double treg = isA ? -(l0v + dmu * l1v + accA) : 0.0;
         const double dinv = 1.0 / dg;
 #pragma unroll
         for (int j = NU - 1; j >= 0; --j) {
@@ -1581,6 +1586,7 @@ template <int NV> struct Solver {
       double reg = 0.0;
       Err er;
       bool fail = false;
+      const double mu_sweep = mu;               // barrier value the sweep's gradients are formed at
       while (!matrix_sweep(mu, reg, x0n2, er, it == 0)) {
         CMPC_SYNC();
         if (reg == 0.0) reg = (reg_last == 0.0) ? 1e-4 : fmax(1e-20, reg_last / 3);
@@ -1592,32 +1598,36 @@ template <int NV> struct Solver {
       const double sm = red_sum(er.sum_mult), nm = red_sum((double)er.n_mult);
       const double sd = fmax(100.0, sm / fmax(nm, 1.0)) / 100.0;
       kkt = fmax(fmax(e_d / sd, e_p), e_c / sd);
+#ifdef CMPC_HOST_EMU
+      if (lane == 0 && getenv("CMPC_EMU_TRACE"))
+        printf("it %3d d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e\n", it, e_d / sd, e_p, e_c / sd, mu, reg);
+#endif
       if (polish >= 0 && kkt > ACC_FACTOR * tol) {
         // polishing lost ground (the step at the final barrier value needed an inertia correction): the point
         // that met the tolerance was written to `out` before the polish and is what is returned
         st = CMPC_CONVERGED; kkt = kkt_saved; use_saved = true; break;
       }
       if (polish < 0) {
+        // best acceptable iterate so far (see the oracle): whatever ends the run, it is what is returned
+        if (kkt <= acc_tol && kkt < kkt_saved) { write_solution(out); kkt_saved = kkt; }
         if (kkt <= tol) {
-          write_solution(out); kkt_saved = kkt;
           polish = POLISH_ITERS; mu = tol / 10;
         } else {
           n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
-          if (n_acc >= ACC_ITERS) { st = CMPC_ACCEPTABLE; break; }
+          if (n_acc >= ACC_ITERS) { st = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = true; break; }
           if (mu <= tol / 10) {                  // at the final barrier value: progress watch
             if (kkt < 0.5 * kkt_best) { kkt_best = kkt; since_best = 0; } else ++since_best;
-            if (since_best >= NOPROG_ITERS && kkt <= acc_tol) { st = CMPC_ACCEPTABLE; break; }
+            if (since_best >= NOPROG_ITERS && kkt_saved <= acc_tol) {
+              st = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = true; break;
+            }
           }
         }
       }
       if (polish == 0) { st = CMPC_CONVERGED; break; }
-      if (it == sp.max_iter) {
-        if (polish >= 0) st = CMPC_CONVERGED;
-        else if (kkt <= acc_tol) st = CMPC_ACCEPTABLE;
-        break;
-      }
-      if (!(kkt < INFINITY) || n_stall >= STALL_ITERS) {
-        st = (kkt <= acc_tol) ? CMPC_ACCEPTABLE : CMPC_NUMERICAL;
+      if (it == sp.max_iter || !(kkt < INFINITY) || n_stall >= STALL_ITERS) {
+        if (polish >= 0) st = CMPC_CONVERGED;                   // (cap reached inside the polish)
+        else if (kkt_saved <= acc_tol) { st = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = true; }
+        else st = (it == sp.max_iter) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
         break;
       }
       if (reg > 0) reg_last = reg;
@@ -1626,7 +1636,7 @@ template <int NV> struct Solver {
         while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
           mu = fmax(tol / 10, fmin(MU_FACTOR * mu, mu * sqrt(mu)));
       double ap, ad;
-      vector_sweeps(mu, ap, ad);
+      vector_sweeps(mu, mu - mu_sweep, ap, ad);
       CMPC_TICK(6);
       n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
       apply_step(mu, ap, ad);

@@ -676,27 +676,29 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
       st->status = CMPC_CONVERGED; kkt = kkt_saved; use_saved = 1; break;
     }
     if (polish < 0) {
+      /* best acceptable iterate so far: at the final barrier value the KKT systems are ill conditioned
+       * (z/s up to 1e+15) and an iterate within a few percent of the tolerance can be followed by worse
+       * ones; whatever ends the run, the best point seen is what is returned */
+      if (kkt <= acc_tol && kkt < kkt_saved) { write_solution(P, W, out); kkt_saved = kkt; }
       if (kkt <= tol) {
-        write_solution(P, W, out); kkt_saved = kkt;
         polish = POLISH_ITERS; mu = tol / 10;
       } else {
         /* IPOPT-style acceptable level: ACC_ITERS consecutive iterates within ACC_FACTOR*tol */
         n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
-        if (n_acc >= ACC_ITERS) { st->status = CMPC_ACCEPTABLE; break; }
+        if (n_acc >= ACC_ITERS) { st->status = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = 1; break; }
         if (mu <= tol / 10) {                      /* at the final barrier value: progress watch */
           if (kkt < 0.5 * kkt_best) { kkt_best = kkt; since_best = 0; } else ++since_best;
-          if (since_best >= NOPROG_ITERS && kkt <= acc_tol) { st->status = CMPC_ACCEPTABLE; break; }
+          if (since_best >= NOPROG_ITERS && kkt_saved <= acc_tol) {
+            st->status = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = 1; break;
+          }
         }
       }
     }
     if (polish == 0) { st->status = CMPC_CONVERGED; break; }
-    if (it == sp->max_iter) {
-      if (polish >= 0) st->status = CMPC_CONVERGED;
-      else if (kkt <= acc_tol) st->status = CMPC_ACCEPTABLE;
-      break;
-    }
-    if (!isfinite(kkt) || n_stall >= STALL_ITERS) {
-      st->status = (isfinite(kkt) && kkt <= acc_tol) ? CMPC_ACCEPTABLE : CMPC_NUMERICAL;
+    if (it == sp->max_iter || !isfinite(kkt) || n_stall >= STALL_ITERS) {
+      if (polish >= 0) st->status = CMPC_CONVERGED;               /* (cap reached inside the polish) */
+      else if (kkt_saved <= acc_tol) { st->status = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = 1; }
+      else st->status = (it == sp->max_iter) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
       break;
     }
     if (polish > 0) --polish;
