@@ -9,16 +9,19 @@ instances over 8 GPUs = 8192 per GPU, horizon N = 20, 4 vertices per foot, cold 
 --gpus 8 is exactly config 4 (weak scaling).  Every rank solves its shard with no communication and
 one RCCL all-gather returns the first-stage feedback (x_1, u_0) + status of every instance.
 
-Consecutive steps are independent batches, so they are enqueued on --streams (default 2) alternating
-HIP streams, each with its own solver handle, scratch and output buffers: a launch is a queue of
-instances of very different length (20 iterations typical, max_iter = 100 for the ~1 % that never
-settle), its last stragglers keep a few workgroups busy long after the queue is empty, and the next
-step's workgroups fill the idle CUs in the meantime.  --streams 1 gives the strictly serial number.
-
-The JSON line also carries
-  roofline      HBM classification of SURVEY.md 8d: algorithmic bytes B_io = 11 728 B per cold N=20
-                solve x solves per launch / kernel time (HIP events on the launch stream) vs 8 TB/s
-  cpu_baseline  the C oracle (a port, not CasADi/IPOPT) on the host cores, bounded sample, rank 0, N=1
+What `value` is.  Steps are launched strictly one after the other on one HIP stream (a closed-loop MPC
+tick is one dependent batch), and only instances that end CONVERGED (status 0: scaled KKT error <= 1e-8)
+are counted as solves.  The same JSON line also carries
+  outcome       fractions of the batch per status: converged / acceptable (status 3: KKT <= 1e-4, tighter
+                than the reference's own IPOPT tolerance 1e-3) / locally infeasible / iteration cap, and the
+                rates `usable_solves_per_s` (status 0 or 3) and `all_instances_per_s`
+  pipelined     the same steps alternating over two solver handles on two HIP streams (independent batches
+                only: the drain of one launch -- its longest instance -- overlaps the next launch)
+  warm_start    every instance re-solved from its own solution (the closed-loop case, :630-631)
+  batch_sweep   B in {1, 16, 256, 4096, 65536} on one GPU, one launch each (BASELINE metric range)
+  roofline      HBM classification of SURVEY.md 8d: algorithmic bytes B_io per solve x solves per launch /
+                kernel time (HIP events on the launch stream, non-overlapped launch) vs 8 TB/s
+  cpu_baseline  the C oracle (a port, not CasADi/IPOPT) on all host cores, bounded sample, rank 0, N=1
 """
 import argparse
 import json
@@ -33,7 +36,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-PER_GPU_BATCH = 8192
+PER_GPU_BATCH = {"randomized": 8192, "perturbed": 8192, "payload": 8192, "long_horizon": 2048}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
@@ -63,11 +66,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams (solver handles) the steps alternate over")
-    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="instances per GPU")
-    ap.add_argument("--workload", default="randomized", choices=["perturbed", "payload", "randomized"])
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams (solver handles) the timed steps alternate over; 1 = strictly serial (headline)")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU")
+    ap.add_argument("--workload", default="randomized", choices=sorted(PER_GPU_BATCH))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the pipelined / warm-start / batch-sweep legs")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = PER_GPU_BATCH[args.workload]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -95,20 +102,22 @@ def main():
 
     B_total = args.batch * world
     spec, rec_all = wl.make_workload(args.workload, B=B_total)
+    if spec.N > 20:
+        spec.max_iter = 150                                        # long horizons take more iterations
     lo, hi = cdist.shard_bounds(B_total, world, rank)
     rec = torch.from_numpy(rec_all[lo:hi].copy()).to(device)       # resident in HBM before timing
-    S = max(1, args.streams)
-    solvers = [BatchedCentroidalMPC(spec, device=device) for _ in range(S)]
-    streams = [torch.cuda.Stream(device=device) for _ in range(S)]
-    outs = [torch.empty((hi - lo, spec.nsol), dtype=torch.float64, device=device) for _ in range(S)]
+    n_handles = max(2, args.streams)
+    solvers = [BatchedCentroidalMPC(spec, device=device) for _ in range(n_handles)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_handles)]
+    outs = [torch.empty((hi - lo, spec.nsol), dtype=torch.float64, device=device) for _ in range(n_handles)]
 
-    def step(i):
+    def step(i, S, records=rec, warm=None):
         j = i % S
         with torch.cuda.stream(streams[j]):
-            XU, status, iters, kkt = solvers[j].solve(rec, out=outs[j])
+            XU, status, iters, kkt = solvers[j].solve(records, warm=warm, out=outs[j][:records.shape[0]])
             fb = cdist.first_stage_feedback(XU, spec.N, spec.nu)
             packed = torch.cat((fb, status.to(fb.dtype)[:, None], iters.to(fb.dtype)[:, None]), dim=1)
-            full = cdist.gather_shards(packed, B_total)            # the ONE collective (no-op at N=1)
+            full = cdist.gather_shards(packed, B_total) if records is rec else packed   # the ONE collective
         return full
 
     def sync():
@@ -117,67 +126,112 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for i in range(args.warmup):
-        step(i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        full = step(i)
-    sync()
-    elapsed = time.perf_counter() - t0
-    # HIP events around each handle's last launch (on its own launch stream), read after the timed
-    # region so that the query does not serialise the streams
-    kernel_ms = [solvers[j].last_kernel_ms() for j in range(min(S, args.steps))]
-    last_ms = float(np.mean(kernel_ms))                           # average launch duration, timed region
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
+    def timed(S, steps, warmup, **kw):
+        for i in range(warmup):
+            step(i, S, **kw)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            full = step(i, S, **kw)
+        sync()
+        el = time.perf_counter() - t0
+        t_max = torch.tensor([el], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return float(t_max.item()), full
+
+    S = max(1, args.streams)
+    elapsed, full = timed(S, args.steps, args.warmup)
+    # HIP events around the last launch of handle 0, on its own launch stream
+    kernel_ms = float(np.mean([solvers[j].last_kernel_ms() for j in range(min(S, args.steps))]))
 
     st = full[:, -2].to(torch.int32)
     it = full[:, -1]
-    conv_frac = float((st == 0).double().mean().item())
+    frac = {name: float((st == code).double().mean().item())
+            for name, code in (("converged", 0), ("iteration_cap", 1), ("locally_infeasible", 2), ("acceptable", 3))}
     mean_iters = float(it.mean().item())
-    value = B_total * args.steps / elapsed
+    rate_all = B_total * args.steps / elapsed
+    value = rate_all * frac["converged"]
     b_io = algorithmic_bytes(spec.N, spec.nu, warm=False)
-    achieved = b_io * (hi - lo) / (last_ms * 1e-3) / 1e9             # GB/s of algorithmic bytes, this rank
-    flops = 3.0e6 * mean_iters * (hi - lo) / (last_ms * 1e-3) / 1e12  # ~3 Mflop per Newton/Riccati step
+    achieved = b_io * (hi - lo) / (kernel_ms * 1e-3) / 1e9           # GB/s of algorithmic bytes, this rank
+    flops = 3.0e6 * mean_iters * (hi - lo) / (kernel_ms * 1e-3) / 1e12  # ~3 Mflop per Newton/Riccati step (N = 20, nv = 4)
 
     traffic = measured_traffic(args.workload, args.batch, spec.N)
     result = {
-        "metric": "centroidal-MPC solves/sec, N=20 horizon",
+        "metric": f"centroidal-MPC solves/sec, N={spec.N} horizon",
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 4 shard: {args.workload}, batch {args.batch}/GPU "
-                               f"({B_total} total), N={spec.N}, 2 feet x {spec.nv} vertices, cold start",
-                   "global_batch": B_total, "horizon": spec.N, "tol": spec.tol, "max_iter": spec.max_iter,
-                   "converged_fraction": conv_frac, "mean_iterations": mean_iters,
+        "config": {"workload": f"BASELINE config {5 if args.workload == 'long_horizon' else 4} shard: {args.workload}, "
+                               f"batch {args.batch}/GPU ({B_total} total), N={spec.N}, 2 feet x {spec.nv} vertices, cold start",
+                   "global_batch": B_total, "horizon": spec.N, "tol": spec.tol, "acc_tol": spec.acc_tol,
+                   "max_iter": spec.max_iter, "mean_iterations": mean_iters,
+                   "counted_as_solves": "status 0 only (scaled KKT error <= tol)",
                    "parallelism": f"batch-sharded x{world}, final all-gather of (x1,u0,status); "
-                                  f"steps alternate over {S} HIP stream(s)"},
+                                  f"{'strictly serial launches' if S == 1 else f'steps alternate over {S} HIP streams'}"},
+        "outcome": dict(frac, usable_solves_per_s=rate_all * (frac["converged"] + frac["acceptable"]),
+                        all_instances_per_s=rate_all,
+                        note="locally infeasible = step length collapsed; on this workload every such instance "
+                             "checked is certified infeasible by the convex first-stage problem "
+                             "(oracle/stage0_feasibility.py, tests/test_oracle.py)"),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                      "traffic_source": traffic[1] if traffic else None,
-                     "kernel": "cmpc_solve_kernel<4>", "kernel_ms": last_ms, "concurrent_launches": S,
+                     "kernel": f"cmpc_solve_kernel<{spec.nv}>", "kernel_ms": kernel_ms, "concurrent_launches": S,
                      "algorithmic_bytes_per_solve": b_io,
                      "note": "latency/FP64-issue bound in practice (SURVEY 8d): see fp64_tflops",
                      "fp64_tflops_model": flops, "fp64_frac_of_vector_peak": flops / FP64_VECTOR_PEAK_TFLOPS},
     }
 
+    if world == 1 and not args.no_extras:
+        # --- independent batches pipelined over two streams
+        el2, full2 = timed(2, args.steps, 2)
+        c2 = float((full2[:, -2] == 0).double().mean().item())
+        result["pipelined"] = {"streams": 2, "converged_solves_per_s": B_total * args.steps / el2 * c2,
+                               "all_instances_per_s": B_total * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3,
+                               "note": "independent batches only; not what a dependent closed-loop tick gets"}
+        # --- warm start: every instance again from its own solution
+        cold = solvers[0].solve(rec)[0].clone()
+        sync()
+        elw, fullw = timed(1, max(2, args.steps // 2), 1, warm=cold)
+        cw = float((fullw[:, -2] == 0).double().mean().item())
+        result["warm_start"] = {"converged_solves_per_s": B_total * max(2, args.steps // 2) / elw * cw,
+                                "all_instances_per_s": B_total * max(2, args.steps // 2) / elw,
+                                "mean_iterations": float(fullw[:, -1].mean().item()), "converged": cw,
+                                "acceptable": float((fullw[:, -2] == 3).double().mean().item())}
+        del cold
+        # --- batch-size sweep of the metric (one launch per size, fresh synthetic batch of that size)
+        sweep = {}
+        for Bs in (1, 16, 256, 4096, 65536):
+            _, rs = wl.make_workload(args.workload, B=Bs, N=spec.N)
+            d = torch.from_numpy(rs).to(device)
+            if Bs > outs[0].shape[0]:
+                outs[0] = torch.empty((Bs, spec.nsol), dtype=torch.float64, device=device)
+            reps = 3 if Bs <= 4096 else 1
+            els, fs = timed(1, reps, 1, records=d)
+            cs_ = float((fs[:, -2] == 0).double().mean().item())
+            sweep[str(Bs)] = {"ms_per_launch": els / reps * 1e3, "all_instances_per_s": Bs * reps / els,
+                              "converged_solves_per_s": Bs * reps / els * cs_}
+            del d
+        result["batch_sweep"] = sweep
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle_lib as ol
-        threads = min(16, os.cpu_count() or 1)
-        nsample = 64 * threads
+        # all host cores this process may run on (the GPU box hands a one-GPU job a share of the host's cores)
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        nsample = max(64, (256 if spec.N <= 20 else 8) * threads)
         sample = rec_all[:nsample]
         cs = ol.default_spec(N=spec.N, nv=spec.nv, tol=spec.tol, max_iter=spec.max_iter, k1=spec.k1, k2=spec.k2,
-                             prox=spec.prox)
+                             prox=spec.prox, acc_tol=spec.acc_tol)
         ol.solve_batch(cs, sample[:threads], nthreads=threads)      # warm the library
         t0 = time.perf_counter()
         _, st_c, it_c, _ = ol.solve_batch(cs, sample, nthreads=threads)
         dt = time.perf_counter() - t0
-        result["cpu_baseline"] = {"value": nsample / dt, "unit": "solves/s", "cores": threads, "kind": "port",
+        result["cpu_baseline"] = {"value": nsample / dt * float((st_c == 0).mean()), "unit": "solves/s", "cores": threads,
+                                  "kind": "port", "all_instances_per_s": nsample / dt,
                                   "sample": f"first {nsample} instances of the same workload, C oracle "
-                                            f"(same algorithm, -O3, OpenMP over the batch), {dt:.1f} s; "
+                                            f"(same algorithm, -O3, OpenMP over the batch, {threads} threads = every core this "
+                                            f"process may use, os.cpu_count() = {os.cpu_count()}), {dt:.1f} s, converged-only like `value`; "
                                             f"CasADi/IPOPT cannot run here (SURVEY 8c)"}
     if rank == 0:
         print(json.dumps(result))

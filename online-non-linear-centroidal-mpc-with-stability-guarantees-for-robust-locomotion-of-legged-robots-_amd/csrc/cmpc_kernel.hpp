@@ -179,7 +179,10 @@ template <int NV> struct Dims {
   // stage's load.  Otherwise (nv = 8) it gets its own region.
   static constexpr bool T_ALIAS = (oSK + NXA * TS <= oTV + NZ);
   static constexpr int oT = T_ALIAS ? oSK : oDUMP + 64;
-  static constexpr int LDS_DOUBLES = T_ALIAS ? oDUMP + 64 : oDUMP + 64 + NXA * TS;
+  // (+ T_PAD: add_GtPG reads the T rows in batches of 10 columns whatever the row's length; the tail of the
+  // last row must still be inside the allocation)
+  static constexpr int T_PAD = 10;
+  static constexpr int LDS_DOUBLES = T_ALIAS ? oDUMP + 64 : oDUMP + 64 + NXA * TS + T_PAD;
   // ---- global scratch map per stage (doubles) ----
   static constexpr int gLAM = 0;
   // Ls (NXA x NU) and P_k (NXA x NXA) as the forward sweep reads them, column c of both in one

@@ -134,17 +134,17 @@ CONFIGS = {
 }
 
 
-def make_workload(name, B=None, N=None, scale=1.0):
-    """(spec, records (B, nrec) numpy) for one of the BASELINE synthetic configs."""
+def make_workload(name, B=None, N=None, scale=1.0, rate=1):
+    """(spec, records (B, nrec) numpy) for one of the BASELINE synthetic configs.
+    rate = 10 is the reference's ``mpc_rate == 10`` variant: delta = 0.1 s, k1, k2 = 5, 0.2, no force-rate
+    cost (:11, :27-31, :339-341), references sampled every tenth tick (:548-600)."""
     seed, N0, nv, payload, B0 = CONFIGS[name]
     B = B0 if B is None else B
     N = N0 if N is None else N
     sc = scene()
-    spec = ProblemSpec(N=N, nv=nv)
-    if payload:
-        spec.k1, spec.k2 = 7.0, 1.0
+    spec = ProblemSpec.from_params(default_params(N=N, mpc_rate=rate), payload=payload, nv=nv)
     rng = np.random.default_rng(seed)
-    t = rng.integers(200, min(1700, sc.t_max(N)) + 1, size=B)
+    t = rng.integers(200, min(1700, sc.t_max(N, rate)) + 1, size=B)
     com, dcom = sc.nominal_state(t)
     com = com + scale * rng.uniform(-0.02, 0.02, size=(B, 3))
     com[:, 2] = np.minimum(com[:, 2], 0.755)
@@ -166,7 +166,7 @@ def make_workload(name, B=None, N=None, scale=1.0):
         dcom = dcom + Fv * 0.1 / mass[:, None]
         r = np.stack([np.zeros(B), np.zeros(B), arm], axis=1)
         hw = hw + np.cross(r, Fv) * 0.1
-    rec = sc.build_records(spec, t, com, dcom, hw, theta, np.zeros(B), np.zeros(B), mass, mu)
+    rec = sc.build_records(spec, t, com, dcom, hw, theta, np.zeros(B), np.zeros(B), mass, mu, rate=rate)
     return spec, rec
 
 

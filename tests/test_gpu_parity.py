@@ -35,28 +35,48 @@ def _solve(gpu, spec, rec, warm=None):
     return out.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), kkt.cpu().numpy()
 
 
-@pytest.mark.parametrize("name,B,N", [("perturbed", 256, 20), ("payload", 512, 20), ("randomized", 512, 20),
-                                        ("perturbed", 128, 10), ("perturbed", 64, 3), ("perturbed", 32, 40),
-                                        ("long_horizon", 64, 10), ("long_horizon", 48, 40)])
-def test_parity_with_oracle(gpu, oracle, name, B, N):
-    spec, rec = wl.make_workload(name, B=B, N=N)
+def _explain_outliers(oracle, cs, spec, rec, got, ref, idx, uprox=None):
+    """Every pair of solutions further apart than the north-star tolerance must be the SAME optimum seen from
+    two points of a flat valley (curvature = the 1e-4 proximal weight against a 1e-8 KKT tolerance): equal
+    objective value, dynamics satisfied, inequalities satisfied.  Nothing else may pass."""
+    nU = 20 * (spec.N + 1)
+    for i in idx:
+        up = None if uprox is None else uprox[i, nU:]
+        f_g, def_g, ineq_g, act_g = oracle.evaluate(cs, rec[i], got[i], uprox=up)
+        f_r, def_r, ineq_r, act_r = oracle.evaluate(cs, rec[i], ref[i], uprox=up)
+        assert abs(f_g - f_r) <= 1e-7 * max(1.0, abs(f_r)), (i, f_g, f_r)
+        assert np.abs(def_g).max() < 1e-7, (i, np.abs(def_g).max())
+        assert ineq_g[act_g == 1].max() <= 1e-7, (i, ineq_g[act_g == 1].max())
+
+
+@pytest.mark.parametrize("name,B,N,rate", [("perturbed", 256, 20, 1), ("payload", 512, 20, 1), ("randomized", 512, 20, 1),
+                                             ("perturbed", 128, 10, 1), ("perturbed", 64, 3, 1), ("perturbed", 32, 40, 1),
+                                             ("long_horizon", 64, 10, 1), ("long_horizon", 48, 40, 1),
+                                             ("perturbed", 128, 10, 10), ("perturbed", 64, 20, 10)])
+def test_parity_with_oracle(gpu, oracle, name, B, N, rate):
+    spec, rec = wl.make_workload(name, B=B, N=N, rate=rate)
     if N > 20:
         spec.max_iter = 150                                   # long horizons take more iterations
+    cs = oracle_spec(oracle, spec)
     got, st, it, kkt = _solve(gpu, spec, rec)
-    ref, st_ref, it_ref, _ = oracle.solve_batch(oracle_spec(oracle, spec), rec)
-    both = np.isin(st, (0, 3)) & np.isin(st_ref, (0, 3))
+    ref, st_ref, it_ref, _ = oracle.solve_batch(cs, rec)
+    ok_g, ok_r = np.isin(st, (0, 3)), np.isin(st_ref, (0, 3))
     # same verdict (usable: converged / acceptable, or not) on (nearly) every instance; whether a slowly
     # converging instance ends as 0 or as 3 depends on rounding (eight iterates in a row within 1e-6)
-    assert (np.isin(st, (0, 3)) != np.isin(st_ref, (0, 3))).sum() <= max(2, (0.03 if N <= 20 else 0.15) * B)
-    assert both.mean() >= 0.85
+    assert (ok_g != ok_r).sum() <= max(2, 0.03 * B)
+    both = ok_g & ok_r
+    assert both.mean() >= (0.85 if rate == 1 else 0.7)        # rate 10: horizons of 1-2 s, more infeasible draws
     err = rel_inf(got[both], ref[both])
-    gerr = group_rel_inf(got[both], ref[both], spec.N, spec.nu)
-    # nearly all instances follow the oracle's path to rounding; a few ill-conditioned ones (inertia
-    # corrections active at the solution) are path dependent at the 1e-4 level in BOTH solvers
-    assert np.median(err) < (1e-9 if N <= 20 else 1e-7)
-    q = (0.97, 0.95) if N <= 20 else (0.75, 0.75)            # long horizons: more path-dependent instances
-    assert np.quantile(err, q[0]) < REL_TOL and np.quantile(gerr, q[1]) < REL_TOL
-    assert (err < 1e-2).all() if N <= 20 else np.quantile(err, 0.9) < 1e-2
+    assert np.median(err) < 1e-9
+    # north star: within 1e-4 rel-inf.  Pairs beyond it are allowed only if they are explained (same optimum,
+    # flat valley) -- checked for every one of them -- and they are few.
+    out = np.where(both)[0][err >= REL_TOL]
+    assert len(out) <= 0.06 * both.sum(), (len(out), int(both.sum()))
+    _explain_outliers(oracle, cs, spec, rec, got, ref, out)
+    # where both solvers met the tight tolerance (status 0) and the optimum is isolated the agreement is to
+    # rounding level
+    tight = (st == 0) & (st_ref == 0)
+    assert np.quantile(rel_inf(got[tight], ref[tight]), 0.9) < 1e-6
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "solver_kat_*.npz"))),
@@ -133,13 +153,7 @@ def test_warm_start_parity_and_speedup(gpu, oracle):
     # objective value and dynamics defect (same optimum, different point of the flat valley).
     err = rel_inf(got[both], ref[both])
     assert np.median(err) < 1e-9 and np.quantile(err, 0.9) < REL_TOL
-    nU = 20 * (spec.N + 1)
-    for i in np.where(both)[0]:
-        up = cold[i, nU:]
-        f_g, def_g, _, _ = oracle.evaluate(cs, rec[i], got[i], uprox=up)
-        f_r, def_r, _, _ = oracle.evaluate(cs, rec[i], ref[i], uprox=up)
-        assert abs(f_g - f_r) <= 1e-7 * max(1.0, abs(f_r))
-        assert np.abs(def_g).max() < 1e-7
+    _explain_outliers(oracle, cs, spec, rec, got, ref, np.where(both)[0], uprox=cold)
 
 
 def test_full_size_properties_domain_randomised(gpu):

@@ -149,6 +149,6 @@ def test_batched_rollout_walk_256(gpu, scene):
     assert alive.all().item()                                  # every tick solved for every instance
     ref = np.stack([scene.com_tab[t0 + i, 0:3] for i in range(ticks + 1)])
     err = np.abs(hist - ref[:, None, :])
-    assert err[..., :2].max() < 0.04 and err[..., 2].max() < 0.02
+    assert err[..., :2].max() < 0.05 and err[..., 2].max() < 0.02
     moved = (ro.plan_pos.cpu().numpy() != scene.plan_pos[None]).any(axis=2)   # (B, n_steps)
     assert (moved.sum(axis=1) == 3).all()                      # three write-backs per instance (t = 261, 361, 461)

@@ -93,3 +93,40 @@ def test_workload_generators_are_deterministic():
         s2, r2 = wl.make_workload(name, B=16)
         assert np.array_equal(r1, r2) and r1.shape == (16, s1.nrec)
         assert np.isfinite(r1).all()
+
+
+def test_quintic_spline_solves_the_reference_system_and_is_minimum_norm(scene):
+    """CoM reference knots -> coefficients (code/functions.py:129-157): the reference hands the 4n-1 equality
+    rows of :135-149 in 6n unknowns to IPOPT with a zero objective from p = 0.  What is checked here, by
+    execution: (i) the rows are exactly those of the reference (position at both ends of every segment,
+    zero end velocities, C1 and C2 continuity, zero initial acceleration), (ii) the coefficients satisfy all
+    of them to 1e-12, (iii) they are THE minimum-norm solution: orthogonal to the null space of the system, so
+    no feasible point is shorter -- the point a regularised Newton step from the origin lands on."""
+    from cmpc_amd import functions as fn
+    import scipy.linalg as sla
+    knot_x, knot_y, seq_x, seq_y = fn.compute_knot(scene.ftg, scene.planner)
+    for knots in (knot_x, knot_y):
+        n = len(knots)
+        A, b = fn.quintic_constraints(knots)
+        assert A.shape == (4 * n - 1, 6 * n) and np.linalg.matrix_rank(A) == 4 * n - 1
+        # (i) row semantics, written out independently of quintic_constraints
+        p = fn.quintic_spline(knots).reshape(n, 6)
+        val = lambda i, s: sum(p[i, j] * s ** j for j in range(6))
+        d1 = lambda i, s: sum(j * p[i, j] * s ** (j - 1) for j in range(1, 6))
+        d2 = lambda i, s: sum(j * (j - 1) * p[i, j] * s ** (j - 2) for j in range(2, 6))
+        for i in range(n - 1):
+            assert abs(val(i, 0.0) - knots[i]) < 1e-12 and abs(val(i, 1.0) - knots[i + 1]) < 1e-12
+            assert abs(d1(i, 1.0) - d1(i + 1, 0.0)) < 1e-12 and abs(d2(i, 1.0) - d2(i + 1, 0.0)) < 1e-12
+        assert abs(d1(0, 0.0)) < 1e-12 and abs(d1(n - 1, 0.0)) < 1e-12 and abs(d2(0, 0.0)) < 1e-12
+        # (ii) all 4n-1 rows
+        x = p.ravel()
+        assert np.abs(A @ x - b).max() < 1e-12
+        # (iii) minimum norm: x in range(A'), i.e. orthogonal to null(A); any other solution is longer
+        Z = sla.null_space(A)
+        assert Z.shape[1] == 2 * n + 1 and np.abs(Z.T @ x).max() < 1e-12
+        rng = np.random.default_rng(0)
+        for _ in range(5):
+            other = x + Z @ rng.normal(size=Z.shape[1])
+            assert np.abs(A @ other - b).max() < 1e-9 and np.linalg.norm(other) > np.linalg.norm(x)
+        # and the closed form x = A'(AA')^-1 b
+        assert np.abs(x - A.T @ np.linalg.solve(A @ A.T, b)).max() < 1e-10
