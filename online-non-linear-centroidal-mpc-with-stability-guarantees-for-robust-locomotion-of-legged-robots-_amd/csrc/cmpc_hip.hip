@@ -20,8 +20,31 @@
 
 namespace {
 
+// Queue order.  A launch ends when its longest instance does, and the instances drawn last decide how long the
+// drain is.  Nine in ten of the long solves (>= 40 iterations) have a contact switch inside the horizon (a
+// change of either contact flag between two nodes); instances without one finish within ~1.7x the mean.  So the
+// switch class is queued first and the drain is left to the short class: order[0 .. n_switch) from the front,
+// the rest from the back (two atomic counters; the order inside a class is arbitrary, results do not depend
+// on it because instances are independent).  counters = {ticket, front, back}.
+__global__ void __launch_bounds__(256) cmpc_order_kernel(int B, int N, const double *__restrict__ recs, int *__restrict__ order,
+                                                         int *__restrict__ counters) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const double *r = recs + (size_t)i * CMPC_NREC(N);
+  double gl = r[24 + 17], gr = r[24 + 18];
+  bool sw = false;
+  for (int k = 1; k <= N; ++k) {
+    const double l = (k < N) ? r[24 + 19 * k + 17] : r[22], q = (k < N) ? r[24 + 19 * k + 18] : r[23];
+    sw = sw || (l != gl) || (q != gr);
+    gl = l; gr = q;
+  }
+  if (sw) order[atomicAdd(counters + 1, 1)] = i;
+  else order[B - 1 - atomicAdd(counters + 2, 1)] = i;
+}
+
 template <int NV>
-__global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_solve_kernel(cmpc::KArgs ka, int *ticket) {
+__global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_solve_kernel(cmpc::KArgs ka, int *ticket,
+                                                                                              const int *__restrict__ order) {
   using D = cmpc::Dims<NV>;
   __shared__ double lds[D::LDS_DOUBLES];
   __shared__ int next;
@@ -33,7 +56,7 @@ __global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_
     const int tk = next;
     __syncthreads();
     if (tk >= ka.B) break;                      // every wave reaches this exit
-    const int p = tk;
+    const int p = order[tk];
     cmpc::Solver<NV> s(ka, lds, slab, ka.recs + (size_t)p * nrec);
     s.solve(ka.warm ? ka.warm + (size_t)p * nsol : nullptr, ka.out + (size_t)p * nsol, ka.status + p,
             ka.iters + p, ka.kkt + p);
@@ -115,7 +138,9 @@ struct cmpc_handle {
   int num_cu = 0;
   size_t slab_doubles = 0;
   double *scratch = nullptr;
-  int *ticket = nullptr;
+  int *ticket = nullptr;                            // {ticket, front, back} of the queue
+  int *order = nullptr;                             // queue order of the last launch, order_cap entries
+  int order_cap = 0;
   long long *prof = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -179,7 +204,7 @@ size_t cmpc_workspace_bytes(const cmpc_spec *spec, int32_t B) {
   // the slab count is bounded by the resident grid, not by B
   int grid = 256 * resident_per_cu(spec->nv);
   if (B > 0 && B < grid) grid = B;
-  return (size_t)grid * slab_doubles(spec) * sizeof(double) + sizeof(int);
+  return (size_t)grid * slab_doubles(spec) * sizeof(double) + 3 * sizeof(int) + (size_t)(B > 0 ? B : 0) * sizeof(int);
 }
 
 int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
@@ -204,7 +229,7 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   if (hipMalloc(&h->prof, 28 * sizeof(long long)) == hipSuccess) (void)hipMemset(h->prof, 0, 28 * sizeof(long long));
 #endif
   if (hipMalloc(&h->scratch, (size_t)h->grid * h->slab_doubles * sizeof(double)) != hipSuccess ||
-      hipMalloc(&h->ticket, sizeof(int)) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
+      hipMalloc(&h->ticket, 3 * sizeof(int)) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess) {
     cmpc_destroy(h);
     return fail(nullptr, "cmpc_create: device allocation failed");
@@ -218,6 +243,7 @@ int cmpc_destroy(cmpc_handle *h) {
   DeviceGuard guard(h->device);
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->ticket) (void)hipFree(h->ticket);
+  if (h->order) (void)hipFree(h->order);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;
@@ -239,12 +265,19 @@ int cmpc_solve_batch(cmpc_handle *h, int32_t B, const double *params, const doub
   ka.scratch = h->scratch; ka.scratch_stride = h->slab_doubles;
   ka.prof = h->prof;
   const int grid = B < h->grid ? B : h->grid;
-  HIP_TRY(h, hipMemsetAsync(h->ticket, 0, sizeof(int), st));
+  if (B > h->order_cap) {                       // grows rarely; hipFree / hipMalloc synchronise the device
+    if (h->order) (void)hipFree(h->order);
+    h->order = nullptr; h->order_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->order, (size_t)B * sizeof(int)));
+    h->order_cap = B;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->ticket, 0, 3 * sizeof(int), st));
   HIP_TRY(h, hipEventRecord(h->ev0, st));
+  hipLaunchKernelGGL(cmpc_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->spec.N, params, h->order, h->ticket);
   if (h->spec.nv == 4)
-    hipLaunchKernelGGL(cmpc_solve_kernel<4>, dim3(grid), dim3(64), 0, st, ka, h->ticket);
+    hipLaunchKernelGGL(cmpc_solve_kernel<4>, dim3(grid), dim3(64), 0, st, ka, h->ticket, h->order);
   else
-    hipLaunchKernelGGL(cmpc_solve_kernel<8>, dim3(grid), dim3(64), 0, st, ka, h->ticket);
+    hipLaunchKernelGGL(cmpc_solve_kernel<8>, dim3(grid), dim3(64), 0, st, ka, h->ticket, h->order);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev1, st));
   h->timed = true;
