@@ -15,7 +15,7 @@ groups=(
 i=0
 for g in "${groups[@]}"; do
   rm -rf "$out/g$i"
-  rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$out/g$i" -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline > "$out/g$i.log" 2>&1 || echo "group $i failed"
+  rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$out/g$i" -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-extras > "$out/g$i.log" 2>&1 || echo "group $i failed"
   echo "group $i done"
   i=$((i+1))
 done
