@@ -9,7 +9,9 @@ import os
 from .problem import CSpec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcmpc_amd.so")
+# CMPC_LIB_PATH: developer knob for A/B measurements of two builds of the HIP library in one GPU session
+# (tools/ab_bench.sh); there is still no fallback of any kind
+LIB_PATH = os.environ.get("CMPC_LIB_PATH") or os.path.join(_HERE, "libcmpc_amd.so")
 
 #: every symbol include/cmpc.h declares
 SYMBOLS = ("cmpc_default_spec", "cmpc_create", "cmpc_destroy", "cmpc_workspace_bytes",

@@ -7,6 +7,7 @@
 // independent: no inter-workgroup communication besides the ticket.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 
@@ -224,6 +225,10 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   }
   h->num_cu = prop.multiProcessorCount;
   h->grid = h->num_cu * resident_per_cu(spec->nv);
+  if (const char *e = getenv("CMPC_WG_PER_CU")) {      // developer knob: fewer resident workgroups per CU (occupancy studies)
+    const int n = atoi(e);
+    if (n >= 1 && n < resident_per_cu(spec->nv)) h->grid = h->num_cu * n;
+  }
   h->slab_doubles = slab_doubles(spec);
 #ifdef CMPC_PROFILE
   if (hipMalloc(&h->prof, 28 * sizeof(long long)) == hipSuccess) (void)hipMemset(h->prof, 0, 28 * sizeof(long long));

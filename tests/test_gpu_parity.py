@@ -101,6 +101,20 @@ def test_golden_vectors(gpu, path):
     assert rel_inf(got, kat["solutions"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "independent_pin_*.npz"))),
+                         ids=lambda p: os.path.basename(p)[16:-4])
+def test_independent_pins(gpu, oracle, path):
+    """The HIP solver against solutions computed without the C oracle (dense interior point on the literal torch
+    restatement, scipy trust-constr): tests/test_independent_pins.py, tests/golden/make_independent_pins.py."""
+    from test_independent_pins import check_against_pin
+    pin = np.load(path)
+    spec = ProblemSpec(N=int(pin["N"]), nv=4, k1=float(pin["k1"]), k2=float(pin["k2"]), tol=1e-9, max_iter=200)
+    got, st, it, kkt = _solve(gpu, spec, pin["record"][None, :])
+    assert st[0] in (0, 3) and kkt[0] < 1e-7
+    cs = oracle_spec(oracle, spec)
+    check_against_pin(pin, got[0], lambda w: oracle.evaluate(cs, pin["record"], w))
+
+
 def test_edge_cases_empty_single_and_ragged_batches(gpu, oracle):
     spec, rec = wl.make_workload("perturbed", B=67, N=10, scale=0.5)
     ref, st_ref, _, _ = oracle.solve_batch(oracle_spec(oracle, spec), rec)
