@@ -154,7 +154,10 @@ def main():
     value = rate_all * frac["converged"]
     b_io = algorithmic_bytes(spec.N, spec.nu, warm=False)
     achieved = b_io * (hi - lo) / (kernel_ms * 1e-3) / 1e9           # GB/s of algorithmic bytes, this rank
-    flops = 3.0e6 * mean_iters * (hi - lo) / (kernel_ms * 1e-3) / 1e12  # ~3 Mflop per Newton/Riccati step (N = 20, nv = 4)
+    # flop model of SURVEY.md 8d (contract figure): per Riccati stage 7/3 nx^3 + 4 nx^2 nu + 2 nx nu^2 + nu^3/3 with
+    # nx = 20, plus 20 % for residual / Jacobian / barrier assembly: ~3 Mflop per Newton step at N = 20, nu = 32
+    per_step = 1.2 * spec.N * (7.0 / 3.0 * 20 ** 3 + 4.0 * 20 ** 2 * spec.nu + 2.0 * 20 * spec.nu ** 2 + spec.nu ** 3 / 3.0)
+    flops = per_step * mean_iters * (hi - lo) / (kernel_ms * 1e-3) / 1e12
 
     traffic = measured_traffic(args.workload, args.batch, spec.N)
     result = {
@@ -219,7 +222,7 @@ def main():
         from oracle import oracle_lib as ol
         # all host cores this process may run on (the GPU box hands a one-GPU job a share of the host's cores)
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        nsample = max(64, (256 if spec.N <= 20 else 8) * threads)
+        nsample = max(64, (256 if spec.N <= 20 else 2) * threads)
         sample = rec_all[:nsample]
         cs = ol.default_spec(N=spec.N, nv=spec.nv, tol=spec.tol, max_iter=spec.max_iter, k1=spec.k1, k2=spec.k2,
                              prox=spec.prox, acc_tol=spec.acc_tol)
