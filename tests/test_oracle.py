@@ -199,3 +199,23 @@ def test_warm_start_is_initial_guess_and_proximal_centre(oracle):
     assert rel_inf(warm, cold)[0] < 1e-3
     # ... but is not identical: the proximal term no longer pulls the inputs towards zero
     assert np.abs(warm - cold).max() > 0
+
+
+def test_locally_infeasible_verdicts_are_certified_by_the_first_stage(oracle):
+    """Classification of the non-converged instances of the bench workload (BASELINE config 4, random pushes up
+    to 100 N): every instance the solver gives up on as locally infeasible (status 2) is PROVEN infeasible by the
+    convex first-stage problem of oracle/stage0_feasibility.py (scipy SLSQP on the epigraph form; shares no code
+    with the solvers), and no instance the solver solves is."""
+    from cmpc_amd import workloads as wl
+    from oracle import nlp_reference as nlp, stage0_feasibility as s0
+    spec, rec = wl.make_workload("randomized", B=384)
+    out, st, it, kkt = oracle.solve_batch(oracle_spec(oracle, spec), rec)
+    ns = nlp.Spec(N=spec.N)
+    bad = np.where(st == 2)[0]
+    assert 4 <= len(bad) <= 30 and (st == 1).sum() == 0           # ~3 % of the draws, none at the iteration cap
+    for i in bad:
+        cert, t = s0.certify(ns, rec[i])
+        assert cert, (i, t)
+    good = np.where(np.isin(st, (0, 3)))[0][:40]
+    assert not any(s0.certify(ns, rec[i])[0] for i in good)
+    assert np.isin(st, (0, 3)).sum() + len(bad) == len(st)         # feasible => solved: 100 % of the feasible draws
