@@ -139,58 +139,50 @@ template <int NV> struct Dims {
   static constexpr int NH = (NZ + 63) / 64;   // rows / columns of the stage block owned by one lane
   static constexpr int PS = NXA + 1;          // odd row strides: conflict-free column access
   static constexpr int LS = NU + 1;
-  // P_{k+1} in LDS: full symmetric square (row stride PS) when the stage block fits one wave; packed lower
-  // triangle for the 8-vertex block, where 5 KB decide between two and three workgroups per CU
-  static constexpr bool P_PACKED = (NZ > 64);
-  static constexpr int P_DOUBLES = P_PACKED ? NXA * (NXA + 1) / 2 : NXA * PS;
+  static constexpr int TH = (NZ + 1) / 2;     // columns per half of T = P [B A]
+  static constexpr int TS = TH | 1;
   // ---- LDS map (doubles) ----
   static constexpr int oM = 0;
   static constexpr int oP = oM + NTRI + (NTRI & 1);
-  // vectors that live across the G'PG / factorisation / backward-vector phases of a stage
-  static constexpr int oXN1 = oP + P_DOUBLES + (P_DOUBLES & 1);
-  static constexpr int oH0 = oXN1 + NXA;      // gradient parts h = h(mu_sweep), dh/dmu of the stage (NZ each)
-  static constexpr int oH1 = oH0 + NZ;
-  static constexpr int oPC1 = oH1 + NZ;       // mu-coefficient of the cost-to-go gradient (NXA)
-  static constexpr int oPC = oPC1 + NXA;
-  // stage evaluation vectors: all dead between build_H and the next stage's load (TV / AL are re-used as
-  // scratch by the backward vector recursion, after the T tile that aliases this block is dead itself)
-  static constexpr int oBLK = oPC + NXA;
-  static constexpr int oXK = oBLK;
+  static constexpr int oXK = oP + NXA * PS + ((NXA * PS) & 1);
   static constexpr int oUK = oXK + NXA;
-  static constexpr int oLAMK = oUK + NU;
+  static constexpr int oXN1 = oUK + NU;
+  static constexpr int oLAMK = oXN1 + NXA;
   static constexpr int oLAMN = oLAMK + NXA;
   static constexpr int oSK = oLAMN + NXA;
   static constexpr int oZK = oSK + NI;
   static constexpr int oGK = oZK + NI;
   static constexpr int oW0 = oGK + NI;        // sigma = z/s
-  static constexpr int oW1 = oGK;             // sigma*(g+s): takes g's slot once g has gone to the slab (barrier-weight loop)
-  static constexpr int oW2 = oW0 + NI;        // 1/s
+  static constexpr int oW1 = oW0 + NI;        // sigma*(g+s)
+  static constexpr int oW2 = oW1 + NI;        // 1/s
   static constexpr int oVR = oW2 + NI;        // r_j   (NF x 3)
   static constexpr int oVDV = oVR + 3 * NF;   // R' v_j
-  static constexpr int oMISC = oVDV + 3 * NF; // 52 scalars (see stage_geometry / stage_ineq)
-  static constexpr int oAL = oMISC + 52;      // Lyapunov gradient (NZ)
-  static constexpr int oGH = oAL + NZ;        // rows 6..8 of [B A] without identity (3 x NZ)
+  static constexpr int oVRV = oVDV + 3 * NF;  // R v_j
+  static constexpr int oMISC = oVRV + 3 * NF; // 64 scalars
+  static constexpr int oAL = oMISC + 64;      // Lyapunov gradient (NZ)
+  static constexpr int oHO = oAL + NZ;
+  static constexpr int oGH = oHO + NZ;        // rows 6..8 of [B A] without identity (3 x NZ)
   static constexpr int oBV = oGH + 3 * NZ;
-  static constexpr int oTV = oBV + NXA;       // NZ temp
+  static constexpr int oPC = oBV + NXA;
+  static constexpr int oTV = oPC + NXA;       // NZ temp
   static constexpr int oUPX = oTV + NZ;
   static constexpr int oSR = oUPX + NU;       // stage record k (19), k-1 (19), header (24)
   static constexpr int oSRP = oSR + 20;
   static constexpr int oHDR = oSRP + 20;
-  static constexpr int oBLK_END = oHDR + 24;
-  static constexpr int oRED = oBLK_END;       // 4 scratch slots
+  static constexpr int oH0 = oHDR + 24;       // gradient parts h = h0 + mu*h1 of the stage (NZ each)
+  static constexpr int oH1 = oH0 + NZ;
+  static constexpr int oPC1 = oH1 + NZ;       // mu-coefficient of the cost-to-go gradient (NXA)
+  static constexpr int oRED = oPC1 + NXA;     // 4 scratch slots
   static constexpr int oDUMP = oRED + 4;      // one write-only slot per lane: target of masked-off read-modify-writes
-  static constexpr int LDS_DOUBLES = oDUMP + 64;
-  // The staging tile of T = P [B A] (NXA rows x TS) aliases the evaluation block; the columns of T are staged in
-  // as few parts as make the tile fit (two for the 60-column block, three for the 92-column one).  add_GtPG reads
-  // the tile's rows in batches of 10 columns whatever the row's length: the over-read of the last row ends in
-  // RED / DUMP, inside the allocation (tests/test_sanitizers.py).
-  static constexpr int tile_ts(int parts) { return ((NZ + parts - 1) / parts) | 1; }
-  static constexpr int NPART = (NXA * tile_ts(2) <= oBLK_END - oBLK) ? 2 : (NXA * tile_ts(3) <= oBLK_END - oBLK) ? 3 : 4;
-  static constexpr int TH = (NZ + NPART - 1) / NPART;   // columns per part
-  static constexpr int TS = TH | 1;
-  static_assert(NXA * TS <= oBLK_END - oBLK, "T tile fits the evaluation block");
-  static_assert(NXA * TS + 10 <= LDS_DOUBLES - oBLK, "over-read of the last T row stays inside LDS");
-  static constexpr int oT = oBLK;
+  // The staging tile of T = P [B A] (NXA x TS) aliases the per-stage evaluation vectors
+  // [oSK, oTV + NZ) when it fits (nv = 4): all of them are dead between build_H and the next
+  // stage's load.  Otherwise (nv = 8) it gets its own region.
+  static constexpr bool T_ALIAS = (oSK + NXA * TS <= oTV + NZ);
+  static constexpr int oT = T_ALIAS ? oSK : oDUMP + 64;
+  // (+ T_PAD: add_GtPG reads the T rows in batches of 10 columns whatever the row's length; the tail of the
+  // last row must still be inside the allocation)
+  static constexpr int T_PAD = 10;
+  static constexpr int LDS_DOUBLES = T_ALIAS ? oDUMP + 64 : oDUMP + 64 + NXA * TS + T_PAD;
   // ---- global scratch map per stage (doubles) ----
   static constexpr int gLAM = 0;
   // Ls (NXA x NU) and P_k (NXA x NXA) as the forward sweep reads them, column c of both in one
@@ -262,11 +254,6 @@ template <int NV> struct Solver {
   }
   CMPC_DEV double *stage(int k) const { return gs + (size_t)k * D::STAGE; }
   CMPC_DEV double &L(int o) const { return lds[o]; }
-  // LDS offset of P[i][j] (symmetric): full square, or packed lower triangle (Dims::P_PACKED)
-  CMPC_DEV static int pidx(int i, int j) {
-    if constexpr (D::P_PACKED) { const int hi = (i > j) ? i : j, lo = (i > j) ? j : i; return D::oP + tri(hi) + lo; }
-    else return D::oP + i * D::PS + j;
-  }
 
   // contact flag gamma_f at node k and k-1 from the staged records
   CMPC_DEV double gam_k(int k, int f) const { return (k == N) ? L(D::oHDR + 22 + f) : L(D::oSR + 17 + f); }
@@ -345,6 +332,7 @@ template <int NV> struct Solver {
       const double rvx = cs * vx - sn * vy, rvy = sn * vx + cs * vy;
       const double dvx = -sn * vx - cs * vy, dvy = cs * vx - sn * vy;
       const double rx = px + rvx - cx, ry = py + rvy - cy, rz = pz - cz;
+      L(D::oVRV + 3 * lane + 0) = rvx; L(D::oVRV + 3 * lane + 1) = rvy; L(D::oVRV + 3 * lane + 2) = 0.0;
       L(D::oVDV + 3 * lane + 0) = dvx; L(D::oVDV + 3 * lane + 1) = dvy; L(D::oVDV + 3 * lane + 2) = 0.0;
       L(D::oVR + 3 * lane + 0) = rx; L(D::oVR + 3 * lane + 1) = ry; L(D::oVR + 3 * lane + 2) = rz;
       tq[3 * lane + 0] = ry * fz - rz * fy; tq[3 * lane + 1] = rz * fx - rx * fz; tq[3 * lane + 2] = rx * fy - ry * fx;
@@ -775,7 +763,7 @@ template <int NV> struct Solver {
     static_assert(QT == 28 || QT == 18 || QT == 14, "LDS batch-read helper sizes");
     constexpr int CT = 10;                                      // columns of M per tile
 #pragma unroll 1
-    for (int half = 0; half < D::NPART; ++half) {
+    for (int half = 0; half < 2; ++half) {
       const int c0 = half * D::TH, c1 = (c0 + D::TH < NZ) ? c0 + D::TH : NZ;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {           // column of T = P [B A] owned by this lane in this half
@@ -790,25 +778,10 @@ template <int NV> struct Solver {
             for (int n = 0; n < 6; ++n) {
               const double g = lg[h][n];
               double v[QT];
-              if constexpr (D::P_PACKED) {
-                // column c of the symmetric P from its packed lower triangle: rows r < c are the column's own
-                // row (P[c][r], contiguous), rows r >= c are strided by the triangle (P[r][c]).  Both candidate
-                // forms of every element are read with immediate offsets in one batch (all addresses are inside
-                // the packed array) and selected per lane: cheaper than per-element address arithmetic, and
-                // hipcc serialises reads at computed addresses (read, wait, fma) at this register pressure.
-                static_assert(QT == 18 && NXA == 36, "symmetric-column helper sizes");
-                const int c = lr[h][n];
-                double hd[QT], tl[QT];
-                if (q0 == 0) lds_read_symcol18_q0(hd, tl, &L(D::oP + tri(c)), &L(D::oP + c));
-                else lds_read_symcol18_q18(hd, tl, &L(D::oP + tri(c) + QT), &L(D::oP + c));
-#pragma unroll
-                for (int q = 0; q < QT; ++q) v[q] = (q0 + q >= c) ? tl[q] : hd[q];
-              } else {
-                const double *pc = &L(D::oP + q0 * D::PS + lr[h][n]);
-                if constexpr (QT == 28) lds_read_strided28<D::PS>(v, pc);
-                else if constexpr (QT == 18) lds_read_strided18<D::PS>(v, pc);
-                else lds_read_strided14<D::PS>(v, pc);
-              }
+              const double *pc = &L(D::oP + q0 * D::PS + lr[h][n]);
+              if constexpr (QT == 28) lds_read_strided28<D::PS>(v, pc);
+              else if constexpr (QT == 18) lds_read_strided18<D::PS>(v, pc);
+              else lds_read_strided14<D::PS>(v, pc);
 #pragma unroll
               for (int q = 0; q < QT; ++q) acc[q] += g * v[q];
             }
@@ -1029,8 +1002,8 @@ template <int NV> struct Solver {
             const int i = 16 * rb + kq + 4 * r, j = 16 * cb + r16;
             const bool in = (i < NXA && j <= i);
             const double v = old[rb][cb][r] - acc[rb][cb][r];
-            *(in ? &L(pidx(i, j)) : dump) = v;
-            if constexpr (!D::P_PACKED) *(in ? &L(pidx(j, i)) : dump) = v;
+            *(in ? &L(D::oP + i * D::PS + j) : dump) = v;
+            *(in ? &L(D::oP + j * D::PS + i) : dump) = v;
           }
     } else {
 #pragma unroll
@@ -1093,7 +1066,7 @@ template <int NV> struct Solver {
         for (int c = 0; c < NXA; ++c) st[D::gLS + c * 64 + lane] = vw[c];
       }
     } else if (k >= 1)
-      for (int e = lane; e < NXA * NXA; e += 64) st[D::gPK + e] = L(pidx(e / NXA, e % NXA));
+      for (int e = lane; e < NXA * NXA; e += 64) st[D::gPK + e] = L(D::oP + (e / NXA) * D::PS + (e % NXA));
   }
 
   // Backward vector recursion of stage k, run inside the matrix sweep while L and Ls are still in
@@ -1217,11 +1190,9 @@ template <int NV> struct Solver {
       CMPC_TICK(12);
       // barrier weights (W2 holds the activity flag on entry); on the very first sweep the slacks and
       // multipliers are created here: s = max(-g, 1e-2), z = mu / s
-      double *st = stage(k);
       for (int r = lane; r < NI; r += 64) {
         const bool act = L(D::oW2 + r) != 0.0;
         const double g = L(D::oGK + r);
-        st[D::gG + r] = g;                     // the row value goes to the slab here: its LDS slot becomes W1 below
         double s = L(D::oSK + r), z = L(D::oZK + r);
         if (init) {
           s = act ? fmax(-g, 1e-2) : 1.0;
@@ -1244,6 +1215,7 @@ template <int NV> struct Solver {
       CMPC_SYNC();
       CMPC_TICK(25);
       build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
+      double *st = stage(k);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const int col = lane + 64 * h;
@@ -1266,6 +1238,7 @@ template <int NV> struct Solver {
         const int c = lane + 64 * h;
         if (c < NZ) { st[D::gGH + c] = L(D::oGH + c); st[D::gGH + D::GHS + c] = L(D::oGH + NZ + c); st[D::gGH + 2 * D::GHS + c] = L(D::oGH + 2 * NZ + c); }
       }
+      for (int r = lane; r < NI; r += 64) st[D::gG + r] = L(D::oGK + r);
       CMPC_TICK(0);
       CMPC_OPAQUE(lane);
       build_H(k, reg, wz);
@@ -1274,12 +1247,11 @@ template <int NV> struct Solver {
       if (k < N) {
         // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG
         if (lane < NXA) {
-          const double *bv = &L(D::oBV);
+          const double *pr = &L(D::oP + lane * D::PS), *bv = &L(D::oBV);
           double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
 #pragma unroll
           for (int q = 0; q < NXA; q += 4) {
-            b0 += L(pidx(lane, q)) * bv[q]; b1 += L(pidx(lane, q + 1)) * bv[q + 1];
-            b2 += L(pidx(lane, q + 2)) * bv[q + 2]; b3 += L(pidx(lane, q + 3)) * bv[q + 3];
+            b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
           }
           const double a = (b0 + b1) + (b2 + b3);
           L(D::oXN1 + lane) = L(D::oPC + lane) + a;       // v0 = p0_{k+1} + P_{k+1} b
@@ -1304,7 +1276,7 @@ template <int NV> struct Solver {
         for (int e = lane; e < NXA * NXA; e += 64) {
           const int i = e / NXA, c = e % NXA;
           const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
-          L(pidx(i, c)) = L(D::oM + tri(NU + hi) + NU + lo);
+          L(D::oP + i * D::PS + c) = L(D::oM + tri(NU + hi) + NU + lo);
         }
         CMPC_SYNC();
       }
