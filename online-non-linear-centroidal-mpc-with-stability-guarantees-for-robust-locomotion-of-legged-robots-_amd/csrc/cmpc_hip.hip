@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_
     const int tk = next;
     __syncthreads();
     if (tk >= ka.B) break;                      // every wave reaches this exit
-    const int p = order[tk];
+    // the queue position comes out of LDS in a vector register; the instance index is wave-uniform, and saying so
+    // keeps the record / output base addresses in scalar registers
+    const int p = __builtin_amdgcn_readfirstlane(order[__builtin_amdgcn_readfirstlane(tk)]);
     cmpc::Solver<NV> s(ka, lds, slab, ka.recs + (size_t)p * nrec);
     s.solve(ka.warm ? ka.warm + (size_t)p * nsol : nullptr, ka.out + (size_t)p * nsol, ka.status + p,
             ka.iters + p, ka.kkt + p);

@@ -219,6 +219,15 @@ template <int NV> struct Dims {
 
 CMPC_DEV int tri(int i) { return i * (i + 1) / 2; }
 
+// Global array addressed as (wave-uniform base) + (32-bit element index).  Written this way hipcc selects the
+// SGPR-base form of the global memory instructions (global_load_dwordx2 v, v_offset, s[base:base+1]); with 64-bit
+// index arithmetic every access went through a 64-bit per-lane address in a VGPR pair, a dozen of which were
+// hoisted to kernel entry, kept live through the whole solve and spilled.  All arrays are far below 4 GB.
+struct GArr {
+  double *p;
+  CMPC_DEV double &operator[](unsigned i) const { return *(double *)((char *)p + (size_t)(i * 8u)); }
+};
+
 template <int NV> struct Solver {
   using D = Dims<NV>;
   static constexpr int NF = D::NF, NU = D::NU, NXA = D::NXA, NZ = D::NZ, NI = D::NI, NH = D::NH;
@@ -226,11 +235,11 @@ template <int NV> struct Solver {
   const KArgs &ka;
   const cmpc_spec &sp;
   double *lds;
-  double *gs;              // this workgroup's scratch slab
-  const double *rec;       // this instance's parameter record
+  GArr gs;                 // this workgroup's scratch slab
+  GArr rec;                // this instance's parameter record (read only)
   int N, lane;
   // global iterate arrays
-  double *gx, *glam, *gdx, *glamn, *gu, *gdu, *gupx, *gsl, *gz, *gds, *gdz;
+  GArr gx, glam, gdx, glamn, gu, gdu, gupx, gsl, gz, gds, gdz;
   // per-lane column list of [B A]: rows / coefficients (id, h0, h1, h2, sp1, sp2)
   int lr[NH][6];
   double lg[NH][6];
@@ -238,21 +247,21 @@ template <int NV> struct Solver {
   long long tprof[28] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 
   CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
-      : ka(a), sp(a.sp), lds(l), gs(g), rec(r), N(a.sp.N), lane(CMPC_LANE) {
-    double *p = gs + (size_t)(N + 1) * D::STAGE;
-    gx = p; p += (size_t)(N + 1) * NXA;
-    glam = p; p += (size_t)(N + 1) * NXA;
-    gdx = p; p += (size_t)(N + 1) * NXA;
-    glamn = p; p += (size_t)(N + 1) * NXA;
-    gu = p; p += (size_t)(N + 1) * NU;
-    gdu = p; p += (size_t)(N + 1) * NU;
-    gupx = p; p += (size_t)(N + 1) * NU;
-    gsl = p; p += (size_t)(N + 1) * NI;
-    gz = p; p += (size_t)(N + 1) * NI;
-    gds = p; p += (size_t)(N + 1) * NI;
-    gdz = p;
+      : ka(a), sp(a.sp), lds(l), gs{g}, rec{const_cast<double *>(r)}, N(a.sp.N), lane(CMPC_LANE) {
+    double *p = g + (size_t)(N + 1) * D::STAGE;
+    gx = GArr{p}; p += (size_t)(N + 1) * NXA;
+    glam = GArr{p}; p += (size_t)(N + 1) * NXA;
+    gdx = GArr{p}; p += (size_t)(N + 1) * NXA;
+    glamn = GArr{p}; p += (size_t)(N + 1) * NXA;
+    gu = GArr{p}; p += (size_t)(N + 1) * NU;
+    gdu = GArr{p}; p += (size_t)(N + 1) * NU;
+    gupx = GArr{p}; p += (size_t)(N + 1) * NU;
+    gsl = GArr{p}; p += (size_t)(N + 1) * NI;
+    gz = GArr{p}; p += (size_t)(N + 1) * NI;
+    gds = GArr{p}; p += (size_t)(N + 1) * NI;
+    gdz = GArr{p};
   }
-  CMPC_DEV double *stage(int k) const { return gs + (size_t)k * D::STAGE; }
+  CMPC_DEV GArr stage(int k) const { return GArr{gs.p + (size_t)k * D::STAGE}; }
   CMPC_DEV double &L(int o) const { return lds[o]; }
 
   // contact flag gamma_f at node k and k-1 from the staged records
@@ -277,16 +286,16 @@ template <int NV> struct Solver {
     const bool in = k < N;
     const int kn = in ? k + 1 : k, ku = in ? k : N - 1, kp = (k >= 1) ? k - 1 : 0;
     const int ix = (lane < NXA) ? lane : 0, iu = (lane < NU) ? lane : 0, ir = (lane < 19) ? lane : 0;
-    const double x0 = gx[(size_t)k * NXA + ix], x1 = gx[(size_t)kn * NXA + ix];
-    const double u0 = gu[(size_t)ku * NU + iu], up = gupx[(size_t)ku * NU + iu];
+    const double x0 = gx[k * NXA + ix], x1 = gx[kn * NXA + ix];
+    const double u0 = gu[ku * NU + iu], up = gupx[ku * NU + iu];
     const double r0 = rec[24 + 19 * ku + ir], r1 = rec[24 + 19 * kp + ir], hd = rec[(lane < 24) ? lane : 0];
     double sv[NIH], zv[NIH];
-    const double l0 = glam[(size_t)k * NXA + ix], l1 = glam[(size_t)kn * NXA + ix];
+    const double l0 = glam[k * NXA + ix], l1 = glam[kn * NXA + ix];
     {
 #pragma unroll
       for (int h = 0; h < NIH; ++h) {
         const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
-        sv[h] = gsl[(size_t)k * NI + rc]; zv[h] = gz[(size_t)k * NI + rc];
+        sv[h] = gsl[k * NI + rc]; zv[h] = gz[k * NI + rc];
       }
     }
     if (lane < NXA) {
@@ -1035,7 +1044,7 @@ template <int NV> struct Solver {
 
   // Store factor blocks of stage k to the global slab (unit stride over lanes).
   CMPC_DEV void store_factors(int k) {
-    double *st = stage(k);
+    const GArr st = stage(k);
     const double *M = &L(D::oM);
     if (k < N) {
       constexpr int NLAM = (NU * NU) / 64;
@@ -1080,7 +1089,7 @@ template <int NV> struct Solver {
   // whenever the barrier value is unchanged, which is every iteration of the end game.
   // Entry: XN1 = p0_{k+1} + P_{k+1} b,  PC1 = p1_{k+1},  H0/H1 = gradient parts of this stage.
   CMPC_DEV void backward_vectors(int k) {
-    double *st = stage(k);
+    const GArr st = stage(k);
     const double *M = &L(D::oM);
     // m = h + [B A]'(.)   (scratch: TV for the mu^0 part, AL for the mu^1 part; both dead here)
 #pragma unroll
@@ -1198,7 +1207,7 @@ template <int NV> struct Solver {
           s = act ? fmax(-g, 1e-2) : 1.0;
           z = act ? mu / s : 0.0;
           L(D::oZK + r) = z;
-          gsl[(size_t)k * NI + r] = s; gz[(size_t)k * NI + r] = z;
+          gsl[k * NI + r] = s; gz[k * NI + r] = z;
         }
         if (act) {
           const double sg = z / s;
@@ -1215,7 +1224,7 @@ template <int NV> struct Solver {
       CMPC_SYNC();
       CMPC_TICK(25);
       build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
-      double *st = stage(k);
+      const GArr st = stage(k);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const int col = lane + 64 * h;
@@ -1327,7 +1336,7 @@ template <int NV> struct Solver {
     CMPC_SYNC();
     for (int k = 0; k <= N; ++k) {
       CMPC_OPAQUE(lane);
-      const double *st = stage(k);
+      const GArr st = stage(k);
       const bool hasA = k < N, hasB = k >= 1;
       // ---- every global load of the stage, before any use
       double gh[3][NH];
@@ -1344,18 +1353,18 @@ template <int NV> struct Solver {
 #pragma unroll
       for (int h = 0; h < NIH; ++h) {
         const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
-        sv[h] = gsl[(size_t)k * NI + rc]; zv[h] = gz[(size_t)k * NI + rc]; gv[h] = st[D::gG + rc];
+        sv[h] = gsl[k * NI + rc]; zv[h] = gz[k * NI + rc]; gv[h] = st[D::gG + rc];
       }
-      const double hw0 = gx[(size_t)k * NXA + 6], hw1 = gx[(size_t)k * NXA + 7], hw2 = gx[(size_t)k * NXA + 8];
+      const double hw0 = gx[k * NXA + 6], hw1 = gx[k * NXA + 7], hw2 = gx[k * NXA + 8];
       double wa[NXA], wb[MERGE ? 1 : NXA], lam[NU];
       {
-        const double *pa = st + D::gLS + ((MERGE || isA) ? lane : 0);
+        const int oa = D::gLS + ((MERGE || isA) ? lane : 0);
 #pragma unroll
-        for (int c = 0; c < NXA; ++c) wa[c] = pa[c * D::LSS];
+        for (int c = 0; c < NXA; ++c) wa[c] = st[oa + c * D::LSS];
         if constexpr (!MERGE) {
-          const double *pb = st + D::gPK + (isB ? lb : 0);
+          const int ob = D::gPK + (isB ? lb : 0);
 #pragma unroll
-          for (int c = 0; c < NXA; ++c) wb[c] = pb[c * NXA];
+          for (int c = 0; c < NXA; ++c) wb[c] = st[ob + c * NXA];
         } else wb[0] = 0.0;
       }
       const int la = isA ? lane : 0;
@@ -1386,7 +1395,7 @@ template <int NV> struct Solver {
           accB = (b0 + b1) + (b2 + b3);
         } else accB = accA;
       }
-      if (hasB && isB) glamn[(size_t)k * NXA + lb] = pv0 + dmu * pv1 + accB;
+      if (hasB && isB) glamn[k * NXA + lb] = pv0 + dmu * pv1 + accB;
       auto slack_dirs = [&](double ldot) {     // ds, dz and the fraction-to-the-boundary bounds of stage k
 #pragma unroll
         for (int h = 0; h < NIH; ++h) {
@@ -1400,7 +1409,7 @@ template <int NV> struct Solver {
               if (ds < 0) lap = fmin(lap, -tau * sr_ / ds);
               if (dz < 0) lad = fmin(lad, -tau * zr / dz);
             }
-            gds[(size_t)k * NI + r] = ds; gdz[(size_t)k * NI + r] = dz;
+            gds[k * NI + r] = ds; gdz[k * NI + r] = dz;
           }
         }
       };
@@ -1425,7 +1434,7 @@ template <int NV> struct Solver {
           if (lane < j) treg -= lam[j] * dj;
         }
         duv = treg * dinv;
-        if (isA) { gdu[(size_t)k * NU + lane] = duv; L(D::oUK + lane) = duv; }
+        if (isA) { gdu[k * NU + lane] = duv; L(D::oUK + lane) = duv; }
       }
       // dense rows: s_r = sum_c GH[r][c] z_c, z = (du, dx), one column per lane
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // s3: Lyapunov gradient . (du, dx)
@@ -1459,7 +1468,7 @@ template <int NV> struct Solver {
         else if (q == 16) a += dx[16] + d * (1 - gr) * du[6 * NV + 7];
         else if (q < 20) a += dx[q] + d * (1 - gr) * du[6 * NV + 3 + q - 17];
         else a += du[3 * (q - 20) + 2];
-        gdx[(size_t)(k + 1) * NXA + q] = a;
+        gdx[(k + 1) * NXA + q] = a;
         L(nxt + q) = a;
       }
       CMPC_SYNC();
@@ -1541,18 +1550,20 @@ template <int NV> struct Solver {
   }
 
   // Initial point: warm start or hover forces; x_0 from the record; carried f_z states.
-  CMPC_DEV void initial_point(const double *warm) {
+  CMPC_DEV void initial_point(const double *warm_) {
+    const GArr warm{const_cast<double *>(warm_)};
+    const bool has_warm = warm_ != nullptr;
     const double m = rec[20];
     for (int e = lane; e < (N + 1) * NXA; e += 64) {
       const int k = e / NXA, i = e % NXA;
       double v = 0.0;
-      if (i < CMPC_NX) v = (warm && k >= 1) ? warm[(size_t)k * CMPC_NX + i] : rec[i];
+      if (i < CMPC_NX) v = (has_warm && k >= 1) ? warm[k * CMPC_NX + i] : rec[i];
       gx[e] = v; glam[e] = 0.0;
     }
     for (int e = lane; e < N * NU; e += 64) {
       const int k = e / NU, i = e % NU;
       double v = 0.0, up = 0.0;
-      if (warm) { v = warm[(size_t)CMPC_NX * (N + 1) + e]; up = v; }
+      if (has_warm) { v = warm[CMPC_NX * (N + 1) + e]; up = v; }
       else if (i < 6 * NV && (i % 3) == 2) {
         const double gl = rec[24 + 19 * k + 17], gr = rec[24 + 19 * k + 18];
         v = m * sp.g / (NV * (gl + gr)) * (((i / 3) < NV) ? gl : gr);
@@ -1562,16 +1573,17 @@ template <int NV> struct Solver {
     CMPC_SYNC_GLOBAL();
     for (int e = lane; e < N * NF; e += 64) {
       const int k = e / NF + 1, j = e % NF;
-      gx[(size_t)k * NXA + CMPC_NX + j] = gu[(size_t)(k - 1) * NU + 3 * j + 2];
+      gx[k * NXA + CMPC_NX + j] = gu[(k - 1) * NU + 3 * j + 2];
     }
     CMPC_SYNC_GLOBAL();
   }
 
   // X (20 x (N+1)) then U (nu x N), the reference's layout.  Reads the iterate arrays as apply_step /
   // initial_point left them (both end with a full fence).
-  CMPC_DEV void write_solution(double *out) {
-    for (int e = lane; e < (N + 1) * CMPC_NX; e += 64) out[e] = gx[(size_t)(e / CMPC_NX) * NXA + (e % CMPC_NX)];
-    for (int e = lane; e < N * NU; e += 64) out[(size_t)CMPC_NX * (N + 1) + e] = gu[e];
+  CMPC_DEV void write_solution(double *out_) {
+    const GArr out{out_};
+    for (int e = lane; e < (N + 1) * CMPC_NX; e += 64) out[e] = gx[(e / CMPC_NX) * NXA + (e % CMPC_NX)];
+    for (int e = lane; e < N * NU; e += 64) out[CMPC_NX * (N + 1) + e] = gu[e];
   }
 
   // ---------------------------------------------------------------------------------------
