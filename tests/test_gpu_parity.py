@@ -238,16 +238,16 @@ def test_device_record_builder_is_bit_exact(gpu, scene):
     the reference's fixtures): integer / copy work, so the bar is bit-exact."""
     from cmpc_amd.solver import DeviceRecordBuilder
     rng = np.random.default_rng(3)
-    for N in (10, 20, 40):
+    for N, rate in ((10, 1), (20, 1), (40, 1), (10, 10), (20, 10)):     # rate 10: the reference's mpc_rate = 10 sampling
         spec = ProblemSpec(N=N)
         B = 3001
-        t = rng.integers(0, scene.t_max(N) + 1, size=B).astype(np.int32)
-        t[:3] = [0, 199, scene.t_max(N)]                     # edges of the tick range
+        t = rng.integers(0, scene.t_max(N, rate) + 1, size=B).astype(np.int32)
+        t[:3] = [0, 199, scene.t_max(N, rate)]               # edges of the tick range
         state = rng.normal(size=(B, 16))
         want = scene.build_records(spec, t, state[:, 0:3], state[:, 3:6], state[:, 6:9], state[:, 9:12], state[:, 12],
-                                   state[:, 13], state[:, 14], state[:, 15])
+                                   state[:, 13], state[:, 14], state[:, 15], rate=rate)
         bld = DeviceRecordBuilder(scene, device="cuda:0")
-        got = bld.build(spec, torch.from_numpy(t).to("cuda:0"), torch.from_numpy(state).to("cuda:0"))
+        got = bld.build(spec, torch.from_numpy(t).to("cuda:0"), torch.from_numpy(state).to("cuda:0"), rate=rate)
         torch.cuda.synchronize()
         assert np.array_equal(got.cpu().numpy(), want)
     # out-of-range ticks are flagged, not read out of bounds

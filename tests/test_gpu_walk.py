@@ -8,7 +8,7 @@ import torch
 from conftest import oracle_spec, rel_inf
 from cmpc_amd import workloads as wl
 from cmpc_amd.problem import ProblemSpec
-from test_walk import build_walk, check_walk_log, measured_hw
+from test_walk import build_walk, check_walk_log, measured_hw, run_rate_10_walk
 
 pytestmark = pytest.mark.gpu
 
@@ -66,6 +66,8 @@ def test_flat_ground_walk_payload_gains_and_rate_10(gpu, oracle):
     assert np.isin(log['status'], (0, 3)).all()
     ref = sc.com_tab[log['t'] + 1, 0:3]
     assert np.abs(log['com'] - ref).max() < 0.03
+    import centroidal_mpc_vertices
+    run_rate_10_walk(centroidal_mpc_vertices.centroidal_mpc, 600)
 
 
 def test_builder_reads_per_instance_plans_bit_exact(gpu, scene):

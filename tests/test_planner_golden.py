@@ -59,6 +59,23 @@ def test_vectorised_builder_equals_scalar_front_half(scene):
         assert np.array_equal(one, batch[b])
 
 
+def test_vectorised_builder_rate_10(scene):
+    """mpc_rate = 10 (:548-600 with rate 10): references sampled at t + (1+i)*10, contact flags at t + i*10."""
+    from cmpc_amd.problem import ProblemSpec as PS
+    spec = PS.from_params(wl.default_params(N=10, mpc_rate=10))
+    assert (spec.delta, spec.k1, spec.k2, spec.w_rate) == (0.1, 5.0, 0.2, 0.0)          # :11, :27-31, :339-341
+    rng = np.random.default_rng(6)
+    ts = rng.integers(0, scene.t_max(10, 10), size=24)
+    B = len(ts)
+    com, dcom, hw, th = (rng.normal(size=(B, 3)) for _ in range(4))
+    batch = scene.build_records(spec, ts, com, dcom, hw, th, np.zeros(B), np.zeros(B), np.full(B, 40.0), np.full(B, 0.5), rate=10)
+    for b, t in enumerate(ts):
+        one = build_record(spec, scene.planner, scene.com_ref, int(t), com[b], dcom[b], hw[b], th[b], 0.0, 0.0, 40.0, 0.5, rate=10)
+        assert np.array_equal(one, batch[b])
+        st = one[24:].reshape(10, 19)
+        assert st[3, 0] == scene.com_ref['pos_x'][int(t) + 40] and st[3, 17] == scene.gl_tab[int(t) + 30]
+
+
 def test_record_layout(scene):
     spec = ProblemSpec(N=10)
     t = 640

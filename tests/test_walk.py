@@ -41,9 +41,9 @@ def make_oracle_backed(oracle):
     return OracleBackedMPC
 
 
-def build_walk(mpc_cls, N=10, hw=None, **kw):
+def build_walk(mpc_cls, N=10, hw=None, mpc_rate=1, **kw):
     sc = wl.scene()
-    params = wl.default_params(N=N)
+    params = wl.default_params(N=N, mpc_rate=mpc_rate)
     planner = FootstepPlanner(wl.VREF, wl.LFOOT0, wl.RFOOT0, params)      # a fresh plan: the MPC rewrites it
     ftg = FootTrajectoryGenerator(sc.initial, planner, params)
     mpc = mpc_cls(sc.initial, planner, params, sc.com_ref, None, None, **kw)
@@ -155,3 +155,21 @@ def test_drop_in_outputs_follow_reference_formulas(oracle):
     assert np.allclose(state['hw']['dot'], 0.01 * f[6:9] * mpc.delta * mpc.mpc_rate, rtol=1e-12, atol=1e-14)
     assert np.array_equal(state['com']['pos'], X[0:3, 1]) and np.array_equal(state['hw']['val'], X[6:9, 1])
     assert state['ang_contact_left']['val'] == X[12, 1] and np.array_equal(state['pos_contact_right']['val'], X[17:20, 1])
+
+
+def run_rate_10_walk(mpc_cls, ticks):
+    """mpc_rate = 10 (simulation.py:203: one solve every tenth tick; delta = 0.1 s, k1, k2 = 5, 0.2, no force-rate cost,
+    :11, :27-31, :339-341): the horizon spans a second, i.e. a whole step."""
+    walk, planner, ftg, mpc, sc = build_walk(mpc_cls, N=10, hw=measured_hw(), mpc_rate=10)
+    assert (mpc.spec.delta, mpc.spec.k1, mpc.spec.k2, mpc.spec.w_rate) == (0.1, 5.0, 0.2, 0.0)
+    log = walk.run(ticks)
+    assert np.isin(log['status'], (0, 3)).all()
+    solved = log['t'] % 10 == 0
+    # x_1 is the state one MPC step (ten ticks) ahead
+    ref = sc.com_tab[log['t'][solved] + 10, 0:3]
+    assert np.abs(log['com'][solved] - ref).max() < 0.06
+    return log
+
+
+def test_closed_loop_walk_rate_10(oracle):
+    run_rate_10_walk(make_oracle_backed(oracle), 400)
