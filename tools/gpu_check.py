@@ -5,9 +5,6 @@ import numpy as np, torch
 import cmpc_amd
 from cmpc_amd import workloads as wl
 from cmpc_amd.solver import BatchedCentroidalMPC
-from cmpc_amd import capi as _capi
-if os.environ.get("CMPC_LIB"):
-    _capi.LIB_PATH = os.path.abspath(os.environ["CMPC_LIB"])   # developer variants
 from oracle import oracle_lib as ol
 
 name = sys.argv[1] if len(sys.argv) > 1 else "perturbed"

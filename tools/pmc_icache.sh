@@ -5,7 +5,7 @@ out=$PWD/gpurun_out/pmc_icache
 rm -rf "$out"; mkdir -p "$out"
 i=0
 for g in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_WAVE_CYCLES SQ_IFETCH SQ_IFETCH_LEVEL"; do
-  rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$out/g$i" -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline > "$out/g$i.log" 2>&1 || echo "group $i failed"
+  rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$out/g$i" -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-extras > "$out/g$i.log" 2>&1 || echo "group $i failed"
   echo "group $i done"; i=$((i+1))
 done
 python3 - "$out" <<'PYEOF'
