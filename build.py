@@ -58,8 +58,23 @@ def build_emu(force=False):
     return out
 
 
+def build_tools(force=False):
+    """Small stand-alone HIP programs the profiling scripts use (tools/ubench): the HBM counter calibration of
+    tools/profile_round.sh and the LDS b128 repro.  Not part of the product library."""
+    outs = []
+    for name in ("hbm_calib", "lds_b128_repro"):
+        src = os.path.join(ROOT, "tools", "ubench", name + ".hip")
+        out = os.path.join(ROOT, "tools", "ubench", name)
+        if force or _newer(out, [src]):
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-o", out, src],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        outs.append(out)
+    return outs
+
+
 if __name__ == "__main__":
     force = "--force" in sys.argv
     print(build_hip(force, verbose="-v" in sys.argv))
     print(build_oracle(force))
     print(build_emu(force))
+    print(build_tools(force))
