@@ -192,7 +192,9 @@ def main():
         c2 = float((full2[:, -2] == 0).double().mean().item())
         result["pipelined"] = {"streams": 2, "converged_solves_per_s": B_total * args.steps / el2 * c2,
                                "all_instances_per_s": B_total * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3,
-                               "note": "independent batches only; not what a dependent closed-loop tick gets"}
+                               "note": "independent batches only; not what a dependent closed-loop tick gets.  "
+                                       "all_instances_per_s here is the definition of round 1's `value` (two streams, "
+                                       "every instance counted): 60.9 k then"}
         # --- warm start: every instance again from its own solution
         cold = solvers[0].solve(rec)[0].clone()
         sync()
