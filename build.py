@@ -58,6 +58,16 @@ def build_emu(force=False):
     return out
 
 
+def build_device_unit(force=False):
+    """GPU-tier unit harness for the device-only primitives (tests/gpu_unit): never loaded by the package."""
+    src = os.path.join(ROOT, "tests", "gpu_unit", "cmpc_device_unit.hip")
+    out = os.path.join(ROOT, "tests", "gpu_unit", "libcmpc_device_unit.so")
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp")]
+    if force or _newer(out, deps):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out, src])
+    return out
+
+
 def build_tools(force=False):
     """Small stand-alone HIP programs the profiling scripts use (tools/ubench): the HBM counter calibration of
     tools/profile_round.sh and the LDS b128 repro.  Not part of the product library."""
@@ -77,4 +87,5 @@ if __name__ == "__main__":
     print(build_hip(force, verbose="-v" in sys.argv))
     print(build_oracle(force))
     print(build_emu(force))
+    print(build_device_unit(force))
     print(build_tools(force))
