@@ -5,35 +5,51 @@
 // with gdb / sanitizers.  It is never loaded by the product package: the product path is the HIP
 // build of the same header and fails loudly without it.
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
+#include <atomic>
 #include <string.h>
 #include <thread>
 #include <vector>
 
 #define CMPC_HOST_EMU 1
 static thread_local int emu_lane_id = 0;
-static pthread_barrier_t emu_barrier;
+// Barrier of the 64 lane threads.  A futex-based pthread barrier costs a wake-up per thread and the solver crosses
+// tens of thousands of them per instance; 64 runnable threads on a handful of cores get through a yielding
+// sense-reversing barrier several times faster.
+struct EmuBarrier { std::atomic<int> count{0}, gen{0}; };
+static EmuBarrier emu_barrier;
+static inline int emu_barrier_wait(EmuBarrier *b) {
+  const int g = b->gen.load(std::memory_order_acquire);
+  if (b->count.fetch_add(1, std::memory_order_acq_rel) == 63) {
+    b->count.store(0, std::memory_order_relaxed);
+    b->gen.store(g + 1, std::memory_order_release);
+  } else {
+    while (b->gen.load(std::memory_order_acquire) == g) sched_yield();
+  }
+  return 0;
+}
 #define CMPC_DEV inline
 #define CMPC_DEVN
 #define CMPC_LANE (emu_lane_id)
-#define CMPC_SYNC() pthread_barrier_wait(&emu_barrier)
-#define CMPC_SYNC_GLOBAL() pthread_barrier_wait(&emu_barrier)
+#define CMPC_SYNC() emu_barrier_wait(&emu_barrier)
+#define CMPC_SYNC_GLOBAL() emu_barrier_wait(&emu_barrier)
 // broadcast of lane `src`'s value: through a shared slot, two barriers
 static double emu_bcast_slot;
 static inline double emu_bcast(double v, int src) {
   if (emu_lane_id == src) emu_bcast_slot = v;
-  pthread_barrier_wait(&emu_barrier);
+  emu_barrier_wait(&emu_barrier);
   double r = emu_bcast_slot;
-  pthread_barrier_wait(&emu_barrier);
+  emu_barrier_wait(&emu_barrier);
   return r;
 }
 #define CMPC_BCAST(v, src) emu_bcast((v), (src))
 static double emu_xor_slots[64];
 static inline double emu_xor(double v, int m) {
   emu_xor_slots[emu_lane_id] = v;
-  pthread_barrier_wait(&emu_barrier);
+  emu_barrier_wait(&emu_barrier);
   double r = emu_xor_slots[emu_lane_id ^ m];
-  pthread_barrier_wait(&emu_barrier);
+  emu_barrier_wait(&emu_barrier);
   return r;
 }
 #define CMPC_XOR(v, m) emu_xor((v), (m))
@@ -43,7 +59,7 @@ struct cmpc_v4d { double v[4]; double &operator[](int i) { return v[i]; } const 
 static double emu_mfma_a[64], emu_mfma_b[64];
 static inline cmpc_v4d emu_mfma(double a, double b, cmpc_v4d c) {
   emu_mfma_a[emu_lane_id] = a; emu_mfma_b[emu_lane_id] = b;
-  pthread_barrier_wait(&emu_barrier);
+  emu_barrier_wait(&emu_barrier);
   const int col = emu_lane_id & 15, rq = emu_lane_id >> 4;
   for (int r = 0; r < 4; ++r) {
     const int row = rq + 4 * r;
@@ -51,7 +67,7 @@ static inline cmpc_v4d emu_mfma(double a, double b, cmpc_v4d c) {
     for (int k = 0; k < 4; ++k) acc += emu_mfma_a[row + 16 * k] * emu_mfma_b[col + 16 * k];
     c[r] = acc;
   }
-  pthread_barrier_wait(&emu_barrier);
+  emu_barrier_wait(&emu_barrier);
   return c;
 }
 #define CMPC_MFMA_F64(a, b, c) emu_mfma((a), (b), (c))
@@ -86,9 +102,8 @@ extern "C" int cmpc_emu_solve_batch(const cmpc_spec *sp, int32_t B, const double
   const double fill = getenv("CMPC_EMU_FILL") ? atof(getenv("CMPC_EMU_FILL")) : 0.0;
   std::vector<double> scratch(nd, fill), lds(nl, fill);
   ka.scratch = scratch.data(); ka.scratch_stride = nd;
-  pthread_barrier_init(&emu_barrier, nullptr, 64);
+  emu_barrier.count.store(0); emu_barrier.gen.store(0);
   if (sp->nv == 4) run_batch<4>(ka, lds.data()); else run_batch<8>(ka, lds.data());
-  pthread_barrier_destroy(&emu_barrier);
   return 0;
 }
 

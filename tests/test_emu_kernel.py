@@ -31,17 +31,25 @@ def test_lds_budget(emu):
     assert emu.cmpc_emu_lds_bytes(8) <= 80 * 1024           # 2 workgroups per CU
 
 
-@pytest.mark.parametrize("name,N,B", [("perturbed", 3, 2), ("payload", 3, 1), ("randomized", 2, 1)])
-def test_kernel_source_matches_oracle(emu, oracle, name, N, B):
-    # the harness runs 64 OS threads per instance and every broadcast is a barrier: keep the cases small
-    # (one of them with two instances, so that slab reuse between instances is exercised)
-    spec, rec = wl.make_workload(name, B=B, N=N)
+@pytest.mark.parametrize("name,N,B,rate", [("perturbed", 3, 2, 1), ("payload", 3, 1, 1), ("randomized", 2, 1, 1),
+                                             ("perturbed", 10, 3, 1), ("randomized", 20, 2, 1), ("perturbed", 10, 2, 10)])
+def test_kernel_source_matches_oracle(emu, oracle, name, N, B, rate):
+    # the harness runs 64 OS threads per instance and every broadcast is a barrier: the cases stay small
+    # (several instances per case, so that slab reuse between instances is exercised)
+    spec, rec = wl.make_workload(name, B=B, N=N, rate=rate)
     cs = oracle_spec(oracle, spec)
     got, st, it, kk = _emu_solve(emu, cs, rec)
     ref, st_ref, it_ref, _ = oracle.solve_batch(cs, rec)
-    assert (st == st_ref).all() and (st == 0).all()
-    assert np.abs(it - it_ref).max() <= 1
-    assert rel_inf(got, ref).max() < 1e-9
+    assert (np.isin(st, (0, 3)) == np.isin(st_ref, (0, 3))).all() and np.isin(st, (0, 3)).all()
+    if N <= 3:
+        assert (st == 0).all() and np.abs(it - it_ref).max() <= 1
+    if rate == 1:
+        assert rel_inf(got, ref).max() < (1e-9 if N <= 3 else 1e-5)
+    else:           # delta = 0.1 s: flat valleys, stops at the acceptable level (tests/test_gpu_parity.py, LEVELS["rate10"])
+        for i in range(B):
+            f_g, d_g, _, _ = oracle.evaluate(cs, rec[i], got[i])
+            f_r, _, _, _ = oracle.evaluate(cs, rec[i], ref[i])
+            assert abs(f_g - f_r) <= 2e-5 * max(1.0, abs(f_r)) and np.abs(d_g).max() < 1e-7
 
 
 def test_kernel_source_eight_vertex_patch(emu, oracle):
@@ -64,3 +72,18 @@ def test_kernel_source_warm_start_and_garbage_memory(emu, oracle, monkeypatch):
     ref, st_ref, it_ref, _ = oracle.solve_batch(cs, rec, warm=cold)
     assert st[0] == 0 and st_ref[0] == 0
     assert rel_inf(got, ref).max() < 1e-9
+
+
+def test_regression_walk_tick_with_ill_conditioned_end_game(emu, oracle):
+    """tests/golden/regress_walk_tick_374.npz: the tick on which the round-1 split of the gradient, h(0) + mu * h1,
+    left a noise floor of eps * |z| * cond on the Newton step (kernel: 100 iterations, KKT 0.24; oracle: 22
+    iterations).  With the split centred on the sweep's barrier value and the best iterate returned, the kernel
+    source ends usable with a KKT error of 1e-8."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress_walk_tick_374.npz"))
+    cs = oracle.default_spec(N=10, nv=4, tol=1e-8, max_iter=100, acc_tol=1e-4)
+    rec, warm = np.ascontiguousarray(d["record"][None]), np.ascontiguousarray(d["warm"][None])
+    got, st, it, kk = _emu_solve(emu, cs, rec, warm=warm)
+    ref, st_ref, it_ref, kk_ref = oracle.solve_batch(cs, rec, warm=warm)
+    assert st[0] in (0, 3) and kk[0] < 1e-7 and it[0] <= 45
+    assert st_ref[0] == 0 and rel_inf(got, ref).max() < 1e-4
