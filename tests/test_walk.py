@@ -173,3 +173,48 @@ def run_rate_10_walk(mpc_cls, ticks):
 
 def test_closed_loop_walk_rate_10(oracle):
     run_rate_10_walk(make_oracle_backed(oracle), 400)
+
+
+def test_closed_loop_ticks_through_the_emulated_kernel(oracle):
+    """The DEVICE source of the solver (tests/emu: 64 lane threads) answering opt.solve() for the drop-in class
+    around a touch-down, write-back tick included (t = 261): the kernel's logic on the reference's own use case,
+    in the CPU tier.  Start state and plan come from an oracle-driven walk up to t = 250."""
+    import ctypes
+    import build as _b
+    emu = ctypes.CDLL(_b.build_emu())
+
+    class EmuBackedMPC(centroidal_mpc):
+        """TEST ONLY: opt.solve() answered by the host emulation of the device source."""
+
+        def _make_solver(self, device):
+            self._cs = oracle_spec(oracle, self.spec)
+            return None
+
+        def _solve_record(self, rec):
+            nsol = self.spec.nsol
+            out, st, it, kk = np.zeros((1, nsol)), np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1)
+            p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+            r = np.ascontiguousarray(rec[None])
+            w = None if self._warm is None else np.ascontiguousarray(self._warm[None])
+            assert emu.cmpc_emu_solve_batch(ctypes.byref(self._cs), 1, p(r), p(w), p(out), p(st), p(it), p(kk)) == 0
+            if st[0] in (0, 3):
+                self._warm = out[0].copy()
+            return out[0], int(st[0]), int(it[0]), float(kk[0])
+
+    hw = measured_hw()
+    lead, planner_o, _, mpc_o, sc = build_walk(make_oracle_backed(oracle), N=10, hw=hw)
+    lead.run(250)
+    walk, planner, ftg, mpc, _ = build_walk(EmuBackedMPC, N=10, hw=hw)
+    walk.time, walk.com, walk.dcom, walk.hw = 250, lead.com.copy(), lead.dcom.copy(), lead.hw.copy()
+    mpc.model_state['theta_hat']['val'] = mpc_o.model_state['theta_hat']['val'].copy()
+    mpc._warm = mpc_o._warm.copy()
+    ref = make_oracle_backed(oracle)
+    for _ in range(22):                                       # t = 250 ... 271
+        lead_state = lead.step()[0]
+        state, contact = walk.step()
+        assert mpc.last_status in (0, 3)
+        assert np.abs(state['com']['pos'] - lead_state['com']['pos']).max() < 1e-6      # same closed loop as the oracle's
+    fired = np.array(walk.log['t'])[np.array(walk.log['counter']) == 1]
+    assert fired.tolist() == [261]
+    idx = planner.get_step_index_at_time(261)
+    assert np.abs(planner.plan[idx + 1]['pos'] - planner_o.plan[idx + 1]['pos']).max() < 1e-7
