@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: batched centroidal-MPC solves per second (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 either arrives from `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment) or, when the command is started bare (`python bench.py --gpus 8`),
+launches its own ranks: the parent spawns N copies of itself as child processes BEFORE anything touches the GPU,
+never initialises HIP and never execs; rank 0 prints the one JSON line; a failed rank makes the parent exit non-zero.
 
 A "step" is one pass of the batched solver over one batch of synthetic parameter records that are
 already resident in HBM.  Workload: the per-GPU shard of BASELINE config 4 (65536 domain-randomised
@@ -33,8 +38,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 PER_GPU_BATCH = {"randomized": 8192, "perturbed": 8192, "payload": 8192, "long_horizon": 2048}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -61,6 +64,44 @@ def measured_traffic(workload, batch, N):
     return best
 
 
+def self_launch(n, argv):
+    """Start the n ranks of `bench.py --gpus n` as child processes (one per GPU, rendezvous on 127.0.0.1) and
+    return the worst exit code.  Runs in a parent that has not imported torch and never touches the GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CMPC_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    worst = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+                    print(f"bench.py: rank {r} exited with code {rc}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:                       # the exact PIDs this parent started, nothing else
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,11 +117,37 @@ def main():
     if args.batch is None:
         args.batch = PER_GPU_BATCH[args.workload]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare: be the launcher (no torch import, no HIP call, no exec in this process)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
+
+    import torch
+    import torch.distributed as dist
+
+    if os.environ.get("CMPC_BENCH_DRYRUN") == "1":
+        # launcher rehearsal for the CPU tier (tests/test_bench_launch.py): rendezvous over gloo, one gather through the
+        # product's dist layer, rank 0 prints a line -- no solver, no GPU.  CMPC_BENCH_DRYRUN_FAIL=r makes rank r fail.
+        import cmpc_amd  # noqa: F401
+        from cmpc_amd import dist as cdist
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if os.environ.get("CMPC_BENCH_DRYRUN_FAIL") == str(rank):
+            raise SystemExit(3)
+        lo, hi = cdist.shard_bounds(10 * world + 3, world, rank)
+        full = cdist.gather_shards(torch.arange(lo, hi, dtype=torch.float64)[:, None], 10 * world + 3)
+        ok = bool((full[:, 0] == torch.arange(10 * world + 3, dtype=torch.float64)).all())
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "gathered_in_order": ok,
+                              "n_ranks_seen": dist.get_world_size() if world > 1 else 1}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP solver has no CPU fallback")
     # CMPC_BENCH_REHEARSAL=1: several ranks share the visible GPU(s) over gloo (to rehearse the N > 1
@@ -162,7 +229,8 @@ def main():
     traffic = measured_traffic(args.workload, args.batch, spec.N)
     result = {
         "metric": f"centroidal-MPC solves/sec, N={spec.N} horizon",
-        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "solves/s", "n_gpus": world,
+        "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE config {5 if args.workload == 'long_horizon' else 4} shard: {args.workload}, "

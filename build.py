@@ -76,8 +76,11 @@ def build_tools(force=False):
         src = os.path.join(ROOT, "tools", "ubench", name + ".hip")
         out = os.path.join(ROOT, "tools", "ubench", name)
         if force or _newer(out, [src]):
-            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-o", out, src],
-                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-o", out, src], capture_output=True, text=True)
+            if r.returncode != 0:                        # profiling helpers only: report, do not fail the product build
+                print(f"build_tools: {name} failed to compile (profiling scripts that need it will not run)\n{r.stderr}",
+                      file=sys.stderr)
+                continue
         outs.append(out)
     return outs
 

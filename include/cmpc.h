@@ -34,7 +34,8 @@ typedef struct cmpc_spec {
   int32_t N;                  /* horizon, params['N'] (:10)                           */
   int32_t nv;                 /* contact vertices per foot: 4 (reference, :55-60) or 8 */
   int32_t max_iter;           /* interior-point iteration cap                         */
-  int32_t reserved;           /* must be 0                                            */
+  int32_t struct_size;        /* sizeof(cmpc_spec): set by cmpc_default_spec, checked by cmpc_create (a caller built
+                                 against an older, shorter layout is refused instead of read past its end)      */
   double delta;               /* world_time_step*mpc_rate (:11)                       */
   double g;                   /* params['g'] (:18)                                    */
   double k1, k2;              /* change-of-coordinates gains (:27-31)                 */
@@ -51,7 +52,7 @@ typedef struct cmpc_spec {
   double prox;                /* proximal weight on U (build-defined)      */
   double relax;               /* inequality relaxation, IPOPT bound_relax_factor 1e-8 */
   double tol;                 /* scaled KKT tolerance                                 */
-  double acc_tol;             /* acceptable level (CMPC_ACCEPTABLE), default 1e-4: tighter than what the
+  double acc_tol;             /* acceptable level (CMPC_ACCEPTABLE), > 0, default 1e-4: tighter than what the
                                  reference's IPOPT configuration (tol = 1e-3, :128; constr_viol_tol and
                                  compl_inf_tol 1e-4 by default) returns as full success              */
 } cmpc_spec;
@@ -65,9 +66,10 @@ typedef struct cmpc_spec {
 enum {
   CMPC_CONVERGED = 0,         /* scaled KKT error <= tol                               */
   CMPC_MAX_ITER = 1,          /* iteration cap reached, error above acc_tol            */
-  CMPC_NUMERICAL = 2,         /* no room to move (locally infeasible: the step length collapsed for several
-                                 iterations), regularisation exhausted or non-finite iterate          */
-  CMPC_INFEASIBLE = 2,        /* the usual meaning of 2: converged to a point of local infeasibility   */
+  CMPC_NUMERICAL = 2,         /* no usable point: the step length collapsed for several iterations (the usual
+                                 case: a point of local infeasibility), regularisation exhausted, or a non-finite
+                                 iterate (e.g. a NaN record from an out-of-range tick)                */
+  CMPC_INFEASIBLE = 2,        /* alias kept for callers: same code, the usual meaning of 2            */
   CMPC_ACCEPTABLE = 3         /* stopped short of tol with error <= acc_tol (IPOPT's "Solved To Acceptable
                                  Level", which CasADi's Opti.solve() returns without raising): iteration cap,
                                  or no progress at the final barrier value                            */
@@ -82,7 +84,10 @@ void cmpc_default_spec(cmpc_spec *spec, int32_t N, int32_t nv);
 int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out);
 int cmpc_destroy(cmpc_handle *h);
 
-/* Device scratch the handle allocates lazily for a batch of B instances. */
+/* Device scratch of a handle for batches of up to B instances: the slabs (bounded by the resident grid of a 256-CU
+ * part, allocated by cmpc_create) plus the queue-order array (4 bytes per instance; (re)allocated by the first
+ * cmpc_solve_batch call with a larger B than any before -- that call synchronises the device and must not be made
+ * under stream capture; later calls with B up to that size allocate nothing). */
 size_t cmpc_workspace_bytes(const cmpc_spec *spec, int32_t B);
 
 /*

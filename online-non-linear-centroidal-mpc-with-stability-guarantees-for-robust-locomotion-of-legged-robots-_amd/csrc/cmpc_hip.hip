@@ -47,7 +47,7 @@ template <int NV>
 __global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_solve_kernel(cmpc::KArgs ka, int *ticket,
                                                                                               const int *__restrict__ order) {
   using D = cmpc::Dims<NV>;
-  __shared__ double lds[D::LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double lds[D::LDS_DOUBLES];
   __shared__ int next;
   double *slab = ka.scratch + (size_t)blockIdx.x * ka.scratch_stride;
   const size_t nrec = CMPC_NREC(ka.sp.N), nsol = CMPC_NSOL(ka.sp.N, NV);
@@ -176,8 +176,9 @@ static int fail(cmpc_handle *h, const std::string &msg) {
   } while (0)
 
 static bool spec_ok(const cmpc_spec *s) {
-  return s && s->N >= 1 && s->N <= CMPC_MAX_N && (s->nv == 4 || s->nv == 8) && s->max_iter >= 1 &&
-         s->delta > 0 && s->tol > 0;
+  return s && s->struct_size == (int32_t)sizeof(cmpc_spec) && s->N >= 1 && s->N <= CMPC_MAX_N &&
+         (s->nv == 4 || s->nv == 8) && s->max_iter >= 1 && s->delta > 0 && s->tol > 0 && s->tol < INFINITY &&
+         s->acc_tol > 0 && s->acc_tol < INFINITY;
 }
 static size_t lds_bytes(int nv) {
   return sizeof(double) * (nv == 4 ? cmpc::Dims<4>::LDS_DOUBLES : cmpc::Dims<8>::LDS_DOUBLES) + 16;
@@ -194,6 +195,7 @@ extern "C" {
 
 void cmpc_default_spec(cmpc_spec *s, int32_t N, int32_t nv) {
   memset(s, 0, sizeof(*s));
+  s->struct_size = (int32_t)sizeof(*s);
   s->N = N; s->nv = nv; s->max_iter = 100;
   s->delta = 0.01; s->g = 9.81; s->k1 = 4.0; s->k2 = 0.1; s->w_rate = 1.0;
   s->w_hw = 1000.0; s->w_cxy = 1.0; s->w_cz_const = 2000.0; s->w_foot = 1000.0; s->w_force = 10.0;
@@ -213,7 +215,7 @@ size_t cmpc_workspace_bytes(const cmpc_spec *spec, int32_t B) {
 int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   if (!out) return fail(nullptr, "cmpc_create: null out pointer");
   *out = nullptr;
-  if (!spec_ok(spec)) return fail(nullptr, "cmpc_create: invalid spec (N in [1,64], nv in {4,8})");
+  if (!spec_ok(spec)) return fail(nullptr, "cmpc_create: invalid spec (struct_size = sizeof(cmpc_spec), N in [1,64], nv in {4,8}, tol > 0, acc_tol > 0)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "cmpc_create: no HIP device");
   if (device < 0 || device >= ndev) return fail(nullptr, "cmpc_create: bad device index");

@@ -184,17 +184,12 @@ template <int NV> struct Dims {
   static constexpr int T_PAD = 10;
   static constexpr int LDS_DOUBLES = T_ALIAS ? oDUMP + 64 : oDUMP + 64 + NXA * TS + T_PAD;
   // ---- global scratch map per stage (doubles) ----
-  static constexpr int gLAM = 0;
-  // Ls (NXA x NU) and P_k (NXA x NXA) as the forward sweep reads them, column c of both in one
-  // 64-wide row when the stage block fits the wave:  W[c][lane] = lane < NU ? Ls[c][lane] : P[c][lane-NU]
-  static constexpr bool W_MERGE = (NZ <= 64);
-  static constexpr int LSS = W_MERGE ? 64 : NU;          // row strides
-  static constexpr int PKS = W_MERGE ? 64 : NXA;
-  static constexpr int gLS = gLAM + NU * NU;
-  static constexpr int gPK = W_MERGE ? gLS + NU : gLS + NXA * NU;
-  static constexpr int gH0 = W_MERGE ? gLS + NXA * 64 : gPK + NXA * NXA;
-  static constexpr int gH1 = gH0 + NZ;
-  static constexpr int gAL = gH1 + NZ;
+  // The factorised stage block as it stands in LDS, a packed lower triangle of NZ rows, copied word for word:
+  // rows 0..NU-1 hold Lambda, row NU+c holds [Ls row c | P_k row c up to the diagonal].  (Round 2 wrote Lambda as a
+  // zero-filled NU x NU square and Ls | P_k as NXA full 64-word rows: 2816 words per stage against 1830.)
+  static constexpr int gM = 0;
+  static constexpr bool W_MERGE = (NZ <= 64);            // forward sweep: lanes >= NU take the P_k columns
+  static constexpr int gAL = ((NTRI + 7) / 8) * 8;
   static constexpr int gGH = gAL + NZ;
   static constexpr int GHS = 64 * NH;      // row stride of the three dense dynamics rows in the slab
   static constexpr int gB = gGH + 3 * GHS;
@@ -223,9 +218,11 @@ CMPC_DEV int tri(int i) { return i * (i + 1) / 2; }
 // SGPR-base form of the global memory instructions (global_load_dwordx2 v, v_offset, s[base:base+1]); with 64-bit
 // index arithmetic every access went through a 64-bit per-lane address in a VGPR pair, a dozen of which were
 // hoisted to kernel entry, kept live through the whole solve and spilled.  All arrays are far below 4 GB.
+typedef double cmpc_v2d __attribute__((vector_size(16)));
 struct GArr {
   double *p;
   CMPC_DEV double &operator[](unsigned i) const { return *(double *)((char *)p + (size_t)(i * 8u)); }
+  CMPC_DEV cmpc_v2d &pair(unsigned i) const { return *(cmpc_v2d *)((char *)p + (size_t)(i * 16u)); }   // 16-byte aligned pairs
 };
 
 template <int NV> struct Solver {
@@ -1013,6 +1010,7 @@ template <int NV> struct Solver {
             const double v = old[rb][cb][r] - acc[rb][cb][r];
             *(in ? &L(D::oP + i * D::PS + j) : dump) = v;
             *(in ? &L(D::oP + j * D::PS + i) : dump) = v;
+            *pm[rb][cb][r] = v;                 // and into the packed image the factor store copies out
           }
     } else {
 #pragma unroll
@@ -1042,40 +1040,27 @@ template <int NV> struct Solver {
     return true;
   }
 
-  // Store factor blocks of stage k to the global slab (unit stride over lanes).
+  // Factor blocks of stage k to the global slab: the packed triangle M (Lambda, Ls, P_k: see Dims::gM) goes out
+  // as it stands, 16 bytes per lane and instruction, no index arithmetic.
   CMPC_DEV void store_factors(int k) {
     const GArr st = stage(k);
-    const double *M = &L(D::oM);
-    if (k < N) {
-      constexpr int NLAM = (NU * NU) / 64;
-      static_assert((NU * NU) % 64 == 0, "whole passes");
-      double vl[NLAM];
+    static_assert(D::NTRI % 2 == 0 && D::oM % 2 == 0 && D::STAGE % 2 == 0, "whole 16-byte pairs");
+    constexpr int NPAIR = D::NTRI / 2, CH = 16;            // pairs; passes per batch of loads
+    const cmpc_v2d *src = reinterpret_cast<const cmpc_v2d *>(&L(D::oM));
+#pragma unroll 1
+    for (int q0 = 0; q0 * 64 < NPAIR; q0 += CH) {
+      cmpc_v2d v[CH];
 #pragma unroll
-      for (int q = 0; q < NLAM; ++q) {       // all LDS reads first (clamped addresses instead of branches)
-        const int e = lane + 64 * q, i = e / NU, j = e % NU;
-        const double v = M[tri(i) + ((j <= i) ? j : i)];
-        vl[q] = (j <= i) ? v : 0.0;
+      for (int q = 0; q < CH; ++q) {             // all LDS reads first; the tail is clamped (duplicate stores of the last pair)
+        const int e = lane + 64 * (q0 + q);
+        v[q] = src[(e < NPAIR) ? e : NPAIR - 1];
       }
 #pragma unroll
-      for (int q = 0; q < NLAM; ++q) st[D::gLAM + lane + 64 * q] = vl[q];
-      if constexpr (!D::W_MERGE)
-        for (int e = lane; e < NXA * NU; e += 64) {
-          const int i = e / NU, j = e % NU;
-          st[D::gLS + e] = M[tri(NU + i) + j];
-        }
+      for (int q = 0; q < CH; ++q) {
+        const int e = lane + 64 * (q0 + q);
+        if (64 * (q0 + q) < NPAIR) st.pair(D::gM / 2 + ((e < NPAIR) ? e : NPAIR - 1)) = v[q];
+      }
     }
-    if constexpr (D::W_MERGE) {
-      const bool a = lane < NU && k < N, b = lane >= NU && lane < NZ && k >= 1;
-      if (a || b) {
-        const double *src = a ? M + tri(NU) + lane : &L(D::oP + lane - NU);
-        double vw[NXA];
-#pragma unroll
-        for (int c = 0; c < NXA; ++c) vw[c] = src[a ? tri(NU + c) - tri(NU) : c * D::PS];
-#pragma unroll
-        for (int c = 0; c < NXA; ++c) st[D::gLS + c * 64 + lane] = vw[c];
-      }
-    } else if (k >= 1)
-      for (int e = lane; e < NXA * NXA; e += 64) st[D::gPK + e] = L(D::oP + (e / NXA) * D::PS + (e % NXA));
   }
 
   // Backward vector recursion of stage k, run inside the matrix sweep while L and Ls are still in
@@ -1357,23 +1342,30 @@ template <int NV> struct Solver {
       }
       const double hw0 = gx[k * NXA + 6], hw1 = gx[k * NXA + 7], hw2 = gx[k * NXA + 8];
       double wa[NXA], wb[MERGE ? 1 : NXA], lam[NU];
-      {
-        const int oa = D::gLS + ((MERGE || isA) ? lane : 0);
-#pragma unroll
-        for (int c = 0; c < NXA; ++c) wa[c] = st[oa + c * D::LSS];
-        if constexpr (!MERGE) {
-          const int ob = D::gPK + (isB ? lb : 0);
-#pragma unroll
-          for (int c = 0; c < NXA; ++c) wb[c] = st[ob + c * NXA];
-        } else wb[0] = 0.0;
-      }
       const int la = isA ? lane : 0;
-      const double l0v = st[D::gL + la], l1v = st[D::gL1 + la], dg = st[D::gLAM + la * NU + la];
+      {
+        // Ls[c][lane] (lanes < NU) and P_k[c][r] out of the packed image: P_k[c][r] sits in row NU + max(c, r)
+        if constexpr (MERGE) {
+          const int lc = (lane < NZ) ? lane : 0;           // lane = NU + r for the P role
+          const int rb = tri(lc) + NU;                    // start of the state part of row NU + r
+#pragma unroll
+          for (int c = 0; c < NXA; ++c) wa[c] = st[D::gM + ((lc < NU || NU + c >= lc) ? tri(NU + c) + lc : rb + c)];
+          wb[0] = 0.0;
+        } else {
+          const int lbc = isB ? lb : 0, rb = tri(NU + lbc) + NU;
+#pragma unroll
+          for (int c = 0; c < NXA; ++c) wa[c] = st[D::gM + tri(NU + c) + la];
+#pragma unroll
+          for (int c = 0; c < NXA; ++c) wb[c] = st[D::gM + ((c >= lbc) ? tri(NU + c) + NU + lbc : rb + c)];
+        }
+      }
+      const double l0v = st[D::gL + la], l1v = st[D::gL1 + la], dg = st[D::gM + tri(la) + la];
       const int lbc = isB ? lb : 0;
       const double pv0 = st[D::gPV + lbc], pv1 = st[D::gPV1 + lbc];
       const double bq = st[D::gB + ((lane < NXA) ? lane : 0)];
+      // column la of Lambda: rows j >= la (the words read for j < la belong to other rows and are never used)
 #pragma unroll
-      for (int j = 0; j < NU; ++j) lam[j] = st[D::gLAM + j * NU + la];
+      for (int j = 0; j < NU; ++j) lam[j] = st[D::gM + tri(j) + la];
       CMPC_TICK(16);
       // ---- Ls' dx (lanes < NU) and P dx (the other role)
       double accA, accB;
@@ -1595,6 +1587,8 @@ template <int NV> struct Solver {
     bool use_saved = false;
     double kkt_best = INFINITY, kkt_saved = INFINITY;
     const double acc_tol = fmax(sp.acc_tol, tol);
+    // every iterate the acceptable-level counter counts is also saved (see the oracle)
+    const double save_tol = fmax(acc_tol, ACC_FACTOR * tol);
     initial_point(warm);
     CMPC_TICK_RESET();
     for (it = 0; it <= sp.max_iter; ++it) {
@@ -1624,7 +1618,7 @@ template <int NV> struct Solver {
       }
       if (polish < 0) {
         // best acceptable iterate so far (see the oracle): whatever ends the run, it is what is returned
-        if (kkt <= acc_tol && kkt < kkt_saved) { write_solution(out); kkt_saved = kkt; }
+        if (kkt <= save_tol && kkt < kkt_saved) { write_solution(out); kkt_saved = kkt; }
         if (kkt <= tol) {
           polish = POLISH_ITERS; mu = tol / 10;
         } else {

@@ -135,7 +135,7 @@ def build_record(spec, planner, com_ref, t, com, dcom, hw, theta_hat, yaw_l, yaw
 class CSpec(ctypes.Structure):
     """C mirror of ``cmpc_spec`` (include/cmpc.h)."""
     _fields_ = [("N", ctypes.c_int32), ("nv", ctypes.c_int32),
-                ("max_iter", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("max_iter", ctypes.c_int32), ("struct_size", ctypes.c_int32),
                 ("delta", ctypes.c_double), ("g", ctypes.c_double),
                 ("k1", ctypes.c_double), ("k2", ctypes.c_double),
                 ("w_rate", ctypes.c_double), ("w_hw", ctypes.c_double),
@@ -150,7 +150,8 @@ class CSpec(ctypes.Structure):
 def to_cspec(spec):
     c = CSpec()
     for name, _ in CSpec._fields_:
-        if name == "reserved":
+        if name == "struct_size":
+            c.struct_size = ctypes.sizeof(CSpec)
             continue
         if name == "box":
             c.box = (ctypes.c_double * 3)(*spec.box)

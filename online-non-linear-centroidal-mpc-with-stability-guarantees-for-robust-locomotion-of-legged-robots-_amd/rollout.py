@@ -98,11 +98,13 @@ class BatchedRollout:
         nxt = self.state.clone()
         nxt[:, 0:12] = x1[:, 0:12]
         if self.hw_measured is not None:
-            nxt[:, 6:9] = self._hw_at(self.t + 1)
+            nxt[:, 6:9] = self._hw_at(self.t + self.rate)
         if push_dv is not None:
             nxt[:, 3:6] += torch.as_tensor(push_dv, dtype=torch.float64, device=self.device)
         self.state = torch.where(ok[:, None], nxt, self.state)
-        self.t = torch.where(ok, self.t + 1, self.t).to(torch.int32)
+        # x_1 is the state delta = rate * world_time_step ahead, and the reference solves every `rate`-th tick
+        # (code/simulation.py:203): schedule time moves with the state
+        self.t = torch.where(ok, self.t + self.rate, self.t).to(torch.int32)
         self.warm = XU if self.warm is None else torch.where(ok[:, None], XU, self.warm)
         return x1, u0, status
 

@@ -627,6 +627,9 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
   int it, n_acc = 0, n_stall = 0, polish = -1, since_best = 0, use_saved = 0;
   double kkt_best = INFINITY, kkt_saved = INFINITY;
   const double acc_tol = fmax(sp->acc_tol, tol);
+  /* every iterate the acceptable-level counter n_acc counts is also saved: with acc_tol < ACC_FACTOR * tol the
+   * counter could otherwise end the run with nothing in `out` */
+  const double save_tol = fmax(acc_tol, ACC_FACTOR * tol);
   double dbg_ap = 0, dbg_ad = 0;
   double kkt = INFINITY;
   double *xn = (double *)malloc(sizeof(double) * nx);
@@ -679,7 +682,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
       /* best acceptable iterate so far: at the final barrier value the KKT systems are ill conditioned
        * (z/s up to 1e+15) and an iterate within a few percent of the tolerance can be followed by worse
        * ones; whatever ends the run, the best point seen is what is returned */
-      if (kkt <= acc_tol && kkt < kkt_saved) { write_solution(P, W, out); kkt_saved = kkt; }
+      if (kkt <= save_tol && kkt < kkt_saved) { write_solution(P, W, out); kkt_saved = kkt; }
       if (kkt <= tol) {
         polish = POLISH_ITERS; mu = tol / 10;
       } else {
@@ -798,6 +801,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
 /* ------------------------------------ exported API -------------------------------------- */
 void cmpc_oracle_default_spec(cmpc_spec *s, int32_t N, int32_t nv) {
   memset(s, 0, sizeof(*s));
+  s->struct_size = (int32_t)sizeof(*s);
   s->N = N; s->nv = nv; s->max_iter = 200;
   s->delta = 0.01; s->g = 9.81; s->k1 = 4.0; s->k2 = 0.1; s->w_rate = 1.0;
   s->w_hw = 1000.0; s->w_cxy = 1.0; s->w_cz_const = 2000.0; s->w_foot = 1000.0; s->w_force = 10.0;

@@ -14,7 +14,7 @@ _LIB = None
 
 class CSpec(ctypes.Structure):
     _fields_ = [("N", ctypes.c_int32), ("nv", ctypes.c_int32),
-                ("max_iter", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("max_iter", ctypes.c_int32), ("struct_size", ctypes.c_int32),
                 ("delta", ctypes.c_double), ("g", ctypes.c_double),
                 ("k1", ctypes.c_double), ("k2", ctypes.c_double),
                 ("w_rate", ctypes.c_double), ("w_hw", ctypes.c_double),

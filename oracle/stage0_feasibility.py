@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY -- rigorous infeasibility certificate from the first stage of the NLP.
+"""TEST INFRASTRUCTURE ONLY -- infeasibility certificate from the first stage of the NLP.
 
 With x_0 fixed (reference code/centroidal_mpc_vertices.py:185), every constraint that involves only
 (x_0, u_0, x_1) is a constraint on the 6*nv contact-force components of u_0 alone:
@@ -14,6 +14,15 @@ The first-stage feasibility problem  min t  s.t.  g_i(u_0) <= t  is therefore CO
 optimum t* proves the whole NLP infeasible (the other stages can only remove points).  It is solved
 here with scipy (SLSQP on the epigraph form, from several starts) and does not share code with the C
 oracle or the HIP solver.  A non-positive t* proves nothing about the later stages.
+
+What SLSQP returns is only an UPPER bound on t* (the largest row at some point).  The certificate is
+therefore taken from the dual side: for multipliers lam >= 0 with sum 1,
+    q(lam) = min_F sum_i lam_i g_i(F)  <=  t*            (weak duality),
+and every g_i is a convex quadratic or linear, so q(lam) is the minimum of ONE convex quadratic, computed in
+closed form.  `certify` derives lam from the stationarity conditions at SLSQP's point (non-negative least
+squares over the active rows) and reports infeasible only if this LOWER bound is positive -- whatever the
+optimiser did, a stalled run can only lose the certificate, never forge one.  (The bound is stated over the
+ball |F| <= F_MAX = 1e5 N, see `dual_lower_bound`.)
 """
 import numpy as np
 import scipy.optimize as so
@@ -89,8 +98,69 @@ def min_violation(spec, par, starts=3, seed=0):
     return best
 
 
+#: the dual bound is taken over contact forces with |F| <= F_MAX newtons (250x the robot's weight): the residual
+#: slope of the Lagrangian along its flat directions (rounding in the fitted multipliers) is charged against it
+F_MAX = 1e5
+
+
+def _quadratic(fun, n):
+    """(Q, c, d) of an exactly quadratic fun(F) = 1/2 F'QF + c'F + d, by differences (exact up to rounding)."""
+    h = 10.0                                           # forces are O(100 N)
+    d = fun(np.zeros(n))
+    E = np.eye(n) * h
+    fp = np.array([fun(E[i]) for i in range(n)]); fm = np.array([fun(-E[i]) for i in range(n)])
+    c = (fp - fm) / (2 * h)
+    Q = np.zeros((n, n))
+    for i in range(n):
+        Q[i, i] = (fp[i] + fm[i] - 2 * d) / (h * h)
+        for j in range(i):
+            Q[i, j] = Q[j, i] = (fun(E[i] + E[j]) - fp[i] - fp[j] + d) / (h * h)
+    return Q, c, d
+
+
+def dual_lower_bound(spec, par, F):
+    """Lower bound on t* = min_F max_i g_i(F) from multipliers fitted at F (see the module docstring);
+    -inf when the fitted multipliers give an unbounded Lagrangian."""
+    lyap, contr, A, nf = _rows(spec, par)
+    n = 3 * nf
+    QL, cL, dL = _quadratic(lyap, n)
+    QC, cC, dC = _quadratic(contr, n)
+    Al, bl = A / 100.0, -spec.relax * np.ones(A.shape[0])
+    vals = np.concatenate([[lyap(F), contr(F)], Al @ F + bl])
+    grads = np.vstack([QL @ F + cL, QC @ F + cC, Al])
+    act = np.where(vals >= vals.max() - 1e-6)[0]
+    # directions in which neither quadratic row has curvature (forces that change neither the net force nor the
+    # torque): the multipliers of the linear rows must cancel there, so those components are weighted up
+    wq, Vq = np.linalg.eigh(QL + QC)
+    Nn = Vq[:, wq <= 1e-9 * wq.max()]
+    # lam >= 0, sum lam = 1, sum lam_i grad_i ~ 0 over the active rows
+    scale = max(1.0, np.abs(grads[act]).max())
+    M = np.vstack([grads[act].T / scale, 1e3 * (Nn.T @ grads[act].T) / scale, 1e3 * np.ones((1, act.size))])
+    lam_a, _ = so.nnls(M, np.concatenate([np.zeros(n + Nn.shape[1]), [1e3]]))
+    if lam_a.sum() <= 0:
+        return -np.inf
+    lam = np.zeros(vals.size); lam[act] = lam_a / lam_a.sum()
+    Q = lam[0] * QL + lam[1] * QC
+    c = lam[0] * cL + lam[1] * cC + Al.T @ lam[2:]
+    d = lam[0] * dL + lam[1] * dC + bl @ lam[2:]
+    w, V = np.linalg.eigh(Q)
+    if w.min() < -1e-9 * max(1.0, w.max()):
+        return -np.inf                                 # cannot happen for these rows; guards the differences
+    pos = w > 1e-10 * max(1.0, w.max())
+    cv = V.T @ c
+    # along the flat directions the Lagrangian is linear with a slope of rounding size (the fitted multipliers are
+    # not exact); it is bounded over the ball |F| <= F_MAX, which is what the bound is stated for
+    flat = np.linalg.norm(cv[~pos]) * F_MAX
+    return d - 0.5 * np.sum(cv[pos] ** 2 / w[pos]) - flat
+
+
 def certify(spec, rec, margin=1e-7):
-    """True if the first stage alone proves the instance infeasible."""
+    """(certified, bound): True only if a dual LOWER bound on the first-stage violation exceeds `margin`,
+    which proves the instance infeasible; `bound` is that lower bound (the primal value SLSQP reached is an
+    upper bound and is used only to find multipliers)."""
     par = nlp.unpack_record(spec, rec)
-    t, _ = min_violation(spec, par)
-    return t > margin, t
+    t, F = min_violation(spec, par)
+    if not (t > margin) or F is None:
+        return False, t
+    lb = dual_lower_bound(spec, par, F)
+    return bool(lb > margin), lb

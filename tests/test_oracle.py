@@ -219,3 +219,18 @@ def test_locally_infeasible_verdicts_are_certified_by_the_first_stage(oracle):
     good = np.where(np.isin(st, (0, 3)))[0][:40]
     assert not any(s0.certify(ns, rec[i])[0] for i in good)
     assert np.isin(st, (0, 3)).sum() + len(bad) == len(st)         # feasible => solved: 100 % of the feasible draws
+
+
+@pytest.mark.parametrize("over", [dict(acc_tol=1e-12), dict(tol=1e-3)])
+def test_status_3_always_carries_a_written_solution(oracle, over):
+    """Round-2 advice: with acc_tol < ACC_FACTOR * tol the acceptable-level counter used to end runs whose iterates
+    had never been saved (status 3, kkt = inf, `out` untouched).  Every iterate the counter counts is saved now."""
+    from cmpc_amd import workloads as wl
+    spec, rec = wl.make_workload("randomized", B=192, N=10)
+    cs = oracle.default_spec(N=10, nv=4, tol=1e-8, max_iter=100)
+    for k, v in over.items():
+        setattr(cs, k, v)
+    got, st, it, kkt = oracle.solve_batch(cs, rec)          # `out` starts as zeros
+    acc = st == 3
+    assert np.isfinite(kkt[acc]).all()
+    assert np.isfinite(got[acc]).all() and (np.abs(got[acc]).max(axis=1) > 0).all()
