@@ -54,6 +54,12 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 // hundreds of lane-derived index computations out of the stage / iteration loops (they were kept live
 // across the whole solve and spilled)
 #define CMPC_OPAQUE(x) asm volatile("" : "+v"(x))
+// the lane id again from the execution mask (two instructions): where it is re-derived the old value need not stay
+// live -- or be spilled -- across the code in front (one wave per workgroup: lane id = thread id)
+#define CMPC_RELANE(x) do { (x) = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); } while (0)
+#endif
+#ifndef CMPC_RELANE
+#define CMPC_RELANE(x) do { } while (0)
 #endif
 
 // Optional phase timers (diagnostic build only, -DCMPC_PROFILE): cycles per phase summed over the
@@ -173,7 +179,9 @@ template <int NV> struct Dims {
   static constexpr int oH1 = oH0 + NZ;
   static constexpr int oPC1 = oH1 + NZ;       // mu-coefficient of the cost-to-go gradient (NXA)
   static constexpr int oRED = oPC1 + NXA;     // 4 scratch slots
-  static constexpr int oDUMP = oRED + 4;      // one write-only slot per lane: target of masked-off read-modify-writes
+  static constexpr int oCOLD = oRED + 4;      // outer-loop state that is touched once per iteration (8 scalars): kept here
+                                              // instead of in registers, where it was spilled to scratch
+  static constexpr int oDUMP = oCOLD + 8;     // one write-only slot per lane: target of masked-off read-modify-writes
   // The staging tile of T = P [B A] (NXA x TS) aliases the per-stage evaluation vectors
   // [oSK, oTV + NZ) when it fits (nv = 4): all of them are dead between build_H and the next
   // stage's load.  Otherwise (nv = 8) it gets its own region.
@@ -498,6 +506,9 @@ template <int NV> struct Solver {
     {
       constexpr int NIH = (NI + 63) / 64;
       const double x2 = L(D::oXK + 2), x6 = L(D::oXK + 6), x7 = L(D::oXK + 7), x8 = L(D::oXK + 8);
+      const double h6 = L(D::oHDR + 6), h7 = L(D::oHDR + 7), h8 = L(D::oHDR + 8);   // hw_0 (record header = x_0)
+      const double hw0n2 = h6 * h6 + h7 * h7 + h8 * h8;
+      (void)x0n2;
       const double red = L(D::oRED) + L(D::oRED + 1) + L(D::oRED + 2);
 #pragma unroll
       for (int h = 0; h < NIH; ++h) {
@@ -516,7 +527,7 @@ template <int NV> struct Solver {
                        : (t == 3) ? -fy - muf * fz : -fz;
         const double g_fr = gs * e - rl;
         const double g_sel = (rc == R_LYAP) ? red - rl : (rc == R_CZ) ? x2 - sp.cz_max - rl
-                           : (rc == R_HWC) ? x6 * x6 + x7 * x7 + x8 * x8 - x0n2 - rl : (is_box ? g_box : g_fr);
+                           : (rc == R_HWC) ? x6 * x6 + x7 * x7 + x8 * x8 - hw0n2 - rl : (is_box ? g_box : g_fr);
         const bool act = (rc == R_LYAP) ? (k < N) : (rc == R_CZ) ? (k >= 1 && k < N) : (rc == R_HWC) ? (k == 1)
                        : (is_box ? (k >= 1 && gk != 0.0) : (k < N && gs != 0.0));
         if (r < NI) {
@@ -697,25 +708,27 @@ template <int NV> struct Solver {
 #pragma unroll
       for (int a = 0; a < 3; ++a)
         cst[f][a] = ((a == ai) ? hV * gam[f] : 0.0) + ((is_force && f == f_i && a == a_i) ? mean_c : 0.0) + gm[f] * cc0[a];
-    // ---- force columns ----
-    double alf[6 * NV], dvv[6 * NV];            // Lyapunov gradient and R'v_j of the force columns, one batch each
-    if constexpr (NV == 4) { lds_read_strided14<1>(*(double (*)[14])&alf[0], al); lds_read_strided14<1>(*(double (*)[14])&alf[10], al + 10);
-                             lds_read_strided14<1>(*(double (*)[14])&dvv[0], &L(D::oVDV)); lds_read_strided14<1>(*(double (*)[14])&dvv[10], &L(D::oVDV + 10)); }
-    else { lds_read_strided28<1>(*(double (*)[28])&alf[0], al); lds_read_strided28<1>(*(double (*)[28])&alf[20], al + 20);
-           lds_read_strided28<1>(*(double (*)[28])&dvv[0], &L(D::oVDV)); lds_read_strided28<1>(*(double (*)[28])&dvv[20], &L(D::oVDV + 20)); }
+    // ---- force columns, one foot at a time (the batch of both feet held 8 NV doubles more than the register file
+    // has to spare at this point: the only spills of the kernel came from here) ----
 #pragma unroll
-    for (int v = 0; v < NF; ++v) {
-      const int f = v / NV;
-      const double dvx = dvv[3 * v], dvy = dvv[3 * v + 1];
-      const double cf0 = f ? cst[1][0] : cst[0][0], cf1 = f ? cst[1][1] : cst[0][1], cf2 = f ? cst[1][2] : cst[0][2];
-      const double gmf = f ? gm[1] : gm[0];
+    for (int f = 0; f < 2; ++f) {
+      constexpr int FC = 3 * NV;                // force columns of one foot
+      double alf[(NV == 4) ? 14 : 28], dvv[(NV == 4) ? 14 : 28];   // Lyapunov gradient and R'v_j of the foot's columns, one batch each
+      if constexpr (NV == 4) { lds_read_strided14<1>(alf, al + f * FC); lds_read_strided14<1>(dvv, &L(D::oVDV + f * FC)); }
+      else { lds_read_strided28<1>(alf, al + f * FC); lds_read_strided28<1>(dvv, &L(D::oVDV + f * FC)); }
+      const double cf0 = cst[f][0], cf1 = cst[f][1], cf2 = cst[f][2];
+      const double gmf = gm[f];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const int j = 3 * v + a;
-        double val = sA * alf[j] + ((a == 0) ? cf0 : (a == 1) ? cf1 : cf2) + gmf * (ccx[a] * dvx + ccy[a] * dvy);
-        if (a < 2) val += (j == j_fr0 + a) ? ((a == 0) ? fr0 : fr1) : 0.0;
-        if (a == 2) val += (j == j_fp) ? -2 * wr_fp : 0.0;
-        *((j < wlim) ? row + j : dump) = val;
+      for (int vv = 0; vv < NV; ++vv) {
+        const double dvx = dvv[3 * vv], dvy = dvv[3 * vv + 1];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const int j = FC * f + 3 * vv + a;
+          double val = sA * alf[3 * vv + a] + ((a == 0) ? cf0 : (a == 1) ? cf1 : cf2) + gmf * (ccx[a] * dvx + ccy[a] * dvy);
+          if (a < 2) val += (j == j_fr0 + a) ? ((a == 0) ? fr0 : fr1) : 0.0;
+          if (a == 2) val += (j == j_fp) ? -2 * wr_fp : 0.0;
+          *((j < wlim) ? row + j : dump) = val;
+        }
       }
     }
     // ---- foot velocity columns: proximal term only ----
@@ -878,6 +891,7 @@ template <int NV> struct Solver {
 #pragma unroll
       for (int c = 0; c < W; ++c) blk[h][c] = ri[(own && C0 + c <= rowi) ? c : 0];   // right of the diagonal: a harmless in-row word
     }
+    CMPC_TICK(19);
 #pragma unroll
     for (int p = 0; p < W / 4; ++p) {
       const int J = C0 + 4 * p;
@@ -946,6 +960,7 @@ template <int NV> struct Solver {
         }
       }
     }
+    CMPC_TICK(20);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int rowi = lane + 64 * h;
@@ -1169,7 +1184,7 @@ template <int NV> struct Solver {
     for (int k = N; k >= 0; --k) {
       const double wz = sp.w_cz_const * 0.5 * ez + sp.w_cz_const * 0.5;
       ez *= e1;
-      CMPC_OPAQUE(lane);
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
       load_stage(k);
       CMPC_TICK(24);
       if (k < N) {
@@ -1208,6 +1223,11 @@ template <int NV> struct Solver {
       if (k >= 1 && lane < NXA) { er.sum_mult += fabs(L(D::oLAMK + lane)); er.n_mult += 1; }
       CMPC_SYNC();
       CMPC_TICK(25);
+      // Hessian rows first: the column lists of [B A] (18 registers per lane) are not live across them
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+      build_H(k, reg, wz);
+      CMPC_TICK(1);
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
       build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
       const GArr st = stage(k);
 #pragma unroll
@@ -1234,10 +1254,7 @@ template <int NV> struct Solver {
       }
       for (int r = lane; r < NI; r += 64) st[D::gG + r] = L(D::oGK + r);
       CMPC_TICK(0);
-      CMPC_OPAQUE(lane);
-      build_H(k, reg, wz);
       CMPC_SYNC();
-      CMPC_TICK(1);
       if (k < N) {
         // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG
         if (lane < NXA) {
@@ -1253,10 +1270,10 @@ template <int NV> struct Solver {
         }
         CMPC_SYNC();                            // the T tile of add_GtPG aliases BV and the other stage vectors
         CMPC_TICK(13);
-        CMPC_OPAQUE(lane);
+        CMPC_RELANE(lane); CMPC_OPAQUE(lane);
         add_GtPG();
         CMPC_TICK(15);
-        CMPC_OPAQUE(lane);
+        CMPC_RELANE(lane); CMPC_OPAQUE(lane);
         if (!factor_stage(k)) return false;
         CMPC_TICK(23);
         backward_vectors(k);
@@ -1274,7 +1291,7 @@ template <int NV> struct Solver {
         }
         CMPC_SYNC();
       }
-      CMPC_OPAQUE(lane);
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
       store_factors(k);
       CMPC_SYNC();
       CMPC_TICK(4);
@@ -1320,7 +1337,7 @@ template <int NV> struct Solver {
     if (lane < NXA) { L(cur + lane) = 0.0; gdx[lane] = 0.0; }
     CMPC_SYNC();
     for (int k = 0; k <= N; ++k) {
-      CMPC_OPAQUE(lane);
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
       const GArr st = stage(k);
       const bool hasA = k < N, hasB = k >= 1;
       // ---- every global load of the stage, before any use
@@ -1581,11 +1598,14 @@ template <int NV> struct Solver {
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void solve(const double *warm, double *out, int32_t *status, int32_t *iters, double *kkt_out) {
     const double tol = sp.tol;
-    const double x0n2 = rec[6] * rec[6] + rec[7] * rec[7] + rec[8] * rec[8];
-    double mu = MU_INIT, reg_last = 0.0, kkt = INFINITY;
+    const double x0n2 = 0.0;                    // |hw_0|^2 is read from the record header in LDS where it is used
+    double mu = MU_INIT, kkt = INFINITY;
     int st = CMPC_MAX_ITER, it = 0, n_acc = 0, n_stall = 0, polish = -1, since_best = 0;
     bool use_saved = false;
-    double kkt_best = INFINITY, kkt_saved = INFINITY;
+    // cold scalars of the outer loop live in LDS (every lane reads the same word; written by every lane with the
+    // same value, fenced by the phases in between)
+    double &reg_last = L(D::oCOLD + 0), &kkt_best = L(D::oCOLD + 1), &kkt_saved = L(D::oCOLD + 2);
+    reg_last = 0.0; kkt_best = INFINITY; kkt_saved = INFINITY;
     const double acc_tol = fmax(sp.acc_tol, tol);
     // every iterate the acceptable-level counter counts is also saved (see the oracle)
     const double save_tol = fmax(acc_tol, ACC_FACTOR * tol);
@@ -1596,10 +1616,11 @@ template <int NV> struct Solver {
       Err er;
       bool fail = false;
       const double mu_sweep = mu;               // barrier value the sweep's gradients are formed at
+      const double rl = reg_last;               // (cold state: read once, ahead of the fences of the sweep)
       while (!matrix_sweep(mu, reg, x0n2, er, it == 0)) {
         CMPC_SYNC();
-        if (reg == 0.0) reg = (reg_last == 0.0) ? 1e-4 : fmax(1e-20, reg_last / 3);
-        else reg *= (reg_last == 0.0) ? 100.0 : 8.0;
+        if (reg == 0.0) reg = (rl == 0.0) ? 1e-4 : fmax(1e-20, rl / 3);
+        else reg *= (rl == 0.0) ? 100.0 : 8.0;
         if (reg > 1e20) { fail = true; break; }
       }
       if (fail) { st = CMPC_NUMERICAL; break; }
@@ -1611,23 +1632,25 @@ template <int NV> struct Solver {
       if (lane == 0 && getenv("CMPC_EMU_TRACE"))
         printf("it %3d d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e\n", it, e_d / sd, e_p, e_c / sd, mu, reg);
 #endif
+      double ks = kkt_saved, kb = kkt_best;     // cold state: every lane reads before any lane writes
+      CMPC_SYNC();
       if (polish >= 0 && kkt > ACC_FACTOR * tol) {
         // polishing lost ground (the step at the final barrier value needed an inertia correction): the point
         // that met the tolerance was written to `out` before the polish and is what is returned
-        st = CMPC_CONVERGED; kkt = kkt_saved; use_saved = true; break;
+        st = CMPC_CONVERGED; kkt = ks; use_saved = true; break;
       }
       if (polish < 0) {
         // best acceptable iterate so far (see the oracle): whatever ends the run, it is what is returned
-        if (kkt <= save_tol && kkt < kkt_saved) { write_solution(out); kkt_saved = kkt; }
+        if (kkt <= save_tol && kkt < ks) { write_solution(out); ks = kkt; kkt_saved = kkt; }
         if (kkt <= tol) {
           polish = POLISH_ITERS; mu = tol / 10;
         } else {
           n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
-          if (n_acc >= ACC_ITERS) { st = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = true; break; }
+          if (n_acc >= ACC_ITERS) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; break; }
           if (mu <= tol / 10) {                  // at the final barrier value: progress watch
-            if (kkt < 0.5 * kkt_best) { kkt_best = kkt; since_best = 0; } else ++since_best;
-            if (since_best >= NOPROG_ITERS && kkt_saved <= acc_tol) {
-              st = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = true; break;
+            if (kkt < 0.5 * kb) { kb = kkt; kkt_best = kkt; since_best = 0; } else ++since_best;
+            if (since_best >= NOPROG_ITERS && ks <= acc_tol) {
+              st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; break;
             }
           }
         }
@@ -1635,7 +1658,7 @@ template <int NV> struct Solver {
       if (polish == 0) { st = CMPC_CONVERGED; break; }
       if (it == sp.max_iter || !(kkt < INFINITY) || n_stall >= STALL_ITERS) {
         if (polish >= 0) st = CMPC_CONVERGED;                   // (cap reached inside the polish)
-        else if (kkt_saved <= acc_tol) { st = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = true; }
+        else if (ks <= acc_tol) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; }
         else st = (it == sp.max_iter) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
         break;
       }

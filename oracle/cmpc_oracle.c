@@ -51,8 +51,21 @@
 #define POLISH_ITERS 1
 /* barrier schedule: start value and linear decrease factor (tuned on the synthetic configs: a large
  * start value centres the first iterates; 0.1 -> 100 cut the mean iteration count from 33 to 23) */
+#ifndef MU_INIT                  /* (-D overrides: tuning experiments only, tools/tune_schedule.py) */
 #define MU_INIT 100.0
+#endif
+#ifndef MU_FACTOR
 #define MU_FACTOR 0.1
+#endif
+#ifndef MU_POWER                 /* superlinear decrease mu <- mu^MU_POWER */
+#define MU_POWER 1.5
+#endif
+#ifndef KAPPA_EPS                /* the barrier problem counts as solved at an error of KAPPA_EPS * mu */
+#define KAPPA_EPS 10.0
+#endif
+#ifndef TAU_MIN                  /* fraction to the boundary */
+#define TAU_MIN 0.99
+#endif
 
 /* inequality row slots of one stage */
 enum { R_LYAP = 0, R_CZ = 1, R_HWC = 2, R_BOX = 3, R_FRIC = 15 };
@@ -706,8 +719,8 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     }
     if (polish > 0) --polish;
     else
-      while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
-        mu = fmax(tol / 10, fmin(MU_FACTOR * mu, mu * sqrt(mu)));
+      while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < KAPPA_EPS * mu)
+        mu = fmax(tol / 10, fmin(MU_FACTOR * mu, (MU_POWER == 1.5) ? mu * sqrt(mu) : pow(mu, MU_POWER)));
     /* ---- barrier-augmented QP data ---- */
     for (int k = 0; k <= N; ++k) {
       double *H = W->H + (size_t)k * nz * nz, *h = W->h + (size_t)k * nz, *ho = W->hobj + (size_t)k * nz;
@@ -737,7 +750,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     if (reg > 0) reg_last = reg;
     riccati_forward(P, W);
     /* ---- slack / multiplier steps, fraction to the boundary ---- */
-    double tau = fmax(0.99, 1 - mu), ap = 1.0, ad = 1.0;
+    double tau = fmax(TAU_MIN, 1 - mu), ap = 1.0, ad = 1.0;
     for (int k = 0; k <= N; ++k) {
       const double *Jg = W->Jg + (size_t)k * ni * nz, *g = W->g + (size_t)k * ni;
       const double *s = W->s + (size_t)k * ni, *z = W->z + (size_t)k * ni;

@@ -97,3 +97,25 @@ def test_kernel_isa_has_no_flat_memory_instructions(tmp_path):
     assert "cmpc_solve_kernel" in isa
     bad = [ln.strip() for ln in isa.splitlines() if ln.strip().startswith(("flat_load", "flat_store", "flat_atomic"))]
     assert not bad, bad[:5]
+
+
+def test_four_vertex_kernel_uses_no_scratch(tmp_path):
+    """The hot kernel (cmpc_solve_kernel<4>) must not spill vector registers: a scratch reload is an exposed memory
+    round trip for a wave that has nothing else to run (round-2 review: Scratch_Size 96 B/lane, 30 VGPR spills).
+    Read from the code-object metadata of the cross-compiled kernel (.private_segment_fixed_size), no GPU needed."""
+    import re
+    import subprocess
+    src = os.path.join(_b.PKG, "csrc", "cmpc_hip.hip")
+    out = tmp_path / "kernel.s"
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                           "-o", str(out), src])
+    isa = out.read_text()
+    # metadata entries: ".name: <mangled>" ... ".private_segment_fixed_size: N" ... ".vgpr_spill_count: N"
+    blocks = [b for b in isa[isa.index("amdhsa.kernels"):].split("  - .agpr_count") if "cmpc_solve_kernelILi4" in b]
+    assert blocks, "kernel metadata not found"
+    meta = blocks[0]
+    scratch = int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", meta).group(1))
+    spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1))
+    lds = int(re.search(r"\.group_segment_fixed_size:\s*(\d+)", meta).group(1))
+    assert scratch == 0 and spills == 0, (scratch, spills)
+    assert 5 * lds <= 160 * 1024                                # five workgroups per CU
