@@ -22,7 +22,8 @@ are counted as solves.  The same JSON line also carries
                 rates `usable_solves_per_s` (status 0 or 3) and `all_instances_per_s`
   pipelined     the same steps alternating over two solver handles on two HIP streams (independent batches
                 only: the drain of one launch -- its longest instance -- overlaps the next launch)
-  warm_start    every instance re-solved from its own solution (the closed-loop case, :630-631)
+  warm_start    every instance re-solved from its own solution and solver state (cmpc_solve_batch_state: the
+                closed-loop entry point; the closed loop proper is tools/walk_demo.py)
   batch_sweep   B in {1, 16, 256, 4096, 65536} on one GPU, one launch each (BASELINE metric range)
   roofline      HBM classification of SURVEY.md 8d: algorithmic bytes B_io per solve x solves per launch /
                 kernel time (HIP events on the launch stream, non-overlapped launch) vs 8 TB/s
@@ -178,10 +179,11 @@ def main():
     streams = [torch.cuda.Stream(device=device) for _ in range(n_handles)]
     outs = [torch.empty((hi - lo, spec.nsol), dtype=torch.float64, device=device) for _ in range(n_handles)]
 
-    def step(i, S, records=rec, warm=None):
+    def step(i, S, records=rec, warm=None, state=None, state_out=None):
         j = i % S
         with torch.cuda.stream(streams[j]):
-            XU, status, iters, kkt = solvers[j].solve(records, warm=warm, out=outs[j][:records.shape[0]])
+            XU, status, iters, kkt = solvers[j].solve(records, warm=warm, out=outs[j][:records.shape[0]],
+                                                      state=state, state_out=state_out)
             fb = cdist.first_stage_feedback(XU, spec.N, spec.nu)
             packed = torch.cat((fb, status.to(fb.dtype)[:, None], iters.to(fb.dtype)[:, None]), dim=1)
             full = cdist.gather_shards(packed, B_total) if records is rec else packed   # the ONE collective
@@ -264,15 +266,17 @@ def main():
                                        "all_instances_per_s here is the definition of round 1's `value` (two streams, "
                                        "every instance counted): 60.9 k then"}
         # --- warm start: every instance again from its own solution
-        cold = solvers[0].solve(rec)[0].clone()
+        state0, state1 = solvers[0].new_state(rec.shape[0]), solvers[0].new_state(rec.shape[0])
+        cold = solvers[0].solve(rec, state_out=state0)[0].clone()
         sync()
-        elw, fullw = timed(1, max(2, args.steps // 2), 1, warm=cold)
+        elw, fullw = timed(1, max(2, args.steps // 2), 1, warm=cold, state=state0, state_out=state1)
         cw = float((fullw[:, -2] == 0).double().mean().item())
         result["warm_start"] = {"converged_solves_per_s": B_total * max(2, args.steps // 2) / elw * cw,
                                 "all_instances_per_s": B_total * max(2, args.steps // 2) / elw,
                                 "mean_iterations": float(fullw[:, -1].mean().item()), "converged": cw,
-                                "acceptable": float((fullw[:, -2] == 3).double().mean().item())}
-        del cold
+                                "acceptable": float((fullw[:, -2] == 3).double().mean().item()),
+                                "note": "same records again, resumed from the solver state of the cold solve"}
+        del cold, state0, state1
         # --- batch-size sweep of the metric (one launch per size, fresh synthetic batch of that size)
         sweep = {}
         for Bs in (1, 16, 256, 4096, 65536):

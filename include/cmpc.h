@@ -61,6 +61,12 @@ typedef struct cmpc_spec {
 #define CMPC_NREC(N) (24 + 19 * (N))
 #define CMPC_NU(nv) (6 * (nv) + 8)
 #define CMPC_NSOL(N, nv) (CMPC_NX * ((N) + 1) + CMPC_NU(nv) * (N))
+/* Solver state carried from one closed-loop tick to the next (cmpc_solve_batch_state): the central-path point the
+ * previous solve passed through at its last barrier value >= 1e-7 -- XU in the layout of out_XU, the dynamics
+ * multipliers ((N+1) x (20 + 2 nv)), slacks and inequality multipliers ((N+1) x (15 + 10 nv) each), then the barrier
+ * value (0 = no valid state), 7 spare words and the contact flags of the N+1 nodes (left, right).  Opaque to callers:
+ * pass last tick's state_out as state_in. */
+#define CMPC_NSTATE(N, nv) (CMPC_NSOL(N, nv) + ((N) + 1) * ((CMPC_NX + 2 * (nv)) + 2 * (15 + 10 * (nv)) + 2) + 8)
 
 /* Per-instance outcome. */
 enum {
@@ -101,6 +107,23 @@ size_t cmpc_workspace_bytes(const cmpc_spec *spec, int32_t B);
 int cmpc_solve_batch(cmpc_handle *h, int32_t B, const double *params, const double *warm_XU,
                      double *out_XU, int32_t *status, int32_t *iters, double *kkt_res,
                      void *stream);
+
+/*
+ * Closed-loop form of cmpc_solve_batch: the solver state of the previous tick comes in, this tick's goes out.
+ *   state_in   [B][CMPC_NSTATE(N,nv)]  last tick's state_out; NULL (or a state whose barrier word is 0) = start as
+ *                                      cmpc_solve_batch does
+ *   state_out  [B][CMPC_NSTATE(N,nv)]  may be NULL; may NOT alias state_in
+ * The state is the interior point method's own iterate at its last barrier value >= 1e-7 -- a point on the central
+ * path of this tick's problem, one level short of the solution -- and the next solve resumes from it at that barrier
+ * value instead of restarting at mu = 100 from the boundary solution (10.0 instead of 17.7 iterations per tick on
+ * the flat-ground walk).  warm_XU keeps its
+ * meaning (previous solution: proximal centre; initial guess only when there is no valid state).  Replaces the
+ * reference's opt.set_initial(sol.value(...)) (code/centroidal_mpc_vertices.py:630-631), which IPOPT likewise uses
+ * for the primal variables only.
+ */
+int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, const double *warm_XU,
+                           const double *state_in, double *out_XU, double *state_out, int32_t *status,
+                           int32_t *iters, double *kkt_res, void *stream);
 
 /* Average kernel time (ms) of the last cmpc_solve_batch on this handle, measured with
  * HIP events on the launch stream; synchronises that stream. */

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CMPC_LIB_PATH") or os.path.join(_HERE, "libcmpc_amd.s
 
 #: every symbol include/cmpc.h declares
 SYMBOLS = ("cmpc_default_spec", "cmpc_create", "cmpc_destroy", "cmpc_workspace_bytes",
-           "cmpc_solve_batch", "cmpc_last_kernel_ms", "cmpc_last_error", "cmpc_version",
+           "cmpc_solve_batch", "cmpc_solve_batch_state", "cmpc_last_kernel_ms", "cmpc_last_error", "cmpc_version",
            "cmpc_tables_create", "cmpc_tables_destroy", "cmpc_build_records",
            "cmpc_tables_set_plan_slots", "cmpc_build_records_planned")
 
@@ -43,6 +43,8 @@ def load():
     lib.cmpc_workspace_bytes.restype = ctypes.c_size_t
     lib.cmpc_solve_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.cmpc_solve_batch.restype = ctypes.c_int
+    lib.cmpc_solve_batch_state.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cmpc_solve_batch_state.restype = ctypes.c_int
     lib.cmpc_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.cmpc_last_kernel_ms.restype = ctypes.c_int
     lib.cmpc_last_error.argtypes = [vp]

@@ -53,6 +53,7 @@ class centroidal_mpc:
 
         self._solver = self._make_solver(device)
         self._warm = None                       # previous solution (device tensor)
+        self._state = None                      # solver state of the previous tick (cmpc_solve_batch_state), device tensor
         self.last_status, self.last_iterations, self.last_kkt = None, 0, float('nan')
         self.x = np.zeros(20)
         self.u = np.zeros(self.spec.nu)
@@ -78,12 +79,15 @@ class centroidal_mpc:
 
     def _solve_record(self, rec):
         """opt.solve() of the reference (:606) for one parameter record -> (solution (nsol,) numpy, status,
-        iterations, kkt).  Warm start = previous primal solution, unshifted (:630-631)."""
+        iterations, kkt).  Warm start = previous primal solution, unshifted (:630-631), plus the interior point
+        method's own state of the previous tick (the central-path point it resumes from, include/cmpc.h)."""
         d_rec = torch.from_numpy(rec[None, :]).to(self._device)
-        out, status, iters, kkt = self._solver.solve(d_rec, warm=self._warm)
+        state_out = self._solver.new_state(1)
+        out, status, iters, kkt = self._solver.solve(d_rec, warm=self._warm, state=self._state, state_out=state_out)
         st = int(status.item())
         if st in (STATUS_CONVERGED, STATUS_ACCEPTABLE):
             self._warm = out                                    # set_initial(U*, X*), unshifted
+            self._state = state_out
         return out[0].cpu().numpy(), st, int(iters.item()), float(kkt.item())
 
     def solve(self, current, t):

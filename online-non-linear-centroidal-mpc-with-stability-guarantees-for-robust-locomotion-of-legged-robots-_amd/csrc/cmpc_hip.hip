@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_
   __shared__ __attribute__((aligned(16))) double lds[D::LDS_DOUBLES];
   __shared__ int next;
   double *slab = ka.scratch + (size_t)blockIdx.x * ka.scratch_stride;
-  const size_t nrec = CMPC_NREC(ka.sp.N), nsol = CMPC_NSOL(ka.sp.N, NV);
+  const size_t nrec = CMPC_NREC(ka.sp.N), nsol = CMPC_NSOL(ka.sp.N, NV), nstate = CMPC_NSTATE(ka.sp.N, NV);
   for (;;) {
     if (threadIdx.x == 0) next = atomicAdd(ticket, 1);
     __syncthreads();
@@ -61,7 +61,8 @@ __global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_
     // keeps the record / output base addresses in scalar registers
     const int p = __builtin_amdgcn_readfirstlane(order[__builtin_amdgcn_readfirstlane(tk)]);
     cmpc::Solver<NV> s(ka, lds, slab, ka.recs + (size_t)p * nrec);
-    s.solve(ka.warm ? ka.warm + (size_t)p * nsol : nullptr, ka.out + (size_t)p * nsol, ka.status + p,
+    s.solve(ka.warm ? ka.warm + (size_t)p * nsol : nullptr, ka.state_in ? ka.state_in + (size_t)p * nstate : nullptr,
+            ka.state_out ? ka.state_out + (size_t)p * nstate : nullptr, ka.out + (size_t)p * nsol, ka.status + p,
             ka.iters + p, ka.kkt + p);
   }
 }
@@ -261,6 +262,12 @@ int cmpc_destroy(cmpc_handle *h) {
 
 int cmpc_solve_batch(cmpc_handle *h, int32_t B, const double *params, const double *warm_XU, double *out_XU,
                      int32_t *status, int32_t *iters, double *kkt_res, void *stream) {
+  return cmpc_solve_batch_state(h, B, params, warm_XU, nullptr, out_XU, nullptr, status, iters, kkt_res, stream);
+}
+
+int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, const double *warm_XU, const double *state_in,
+                           double *out_XU, double *state_out, int32_t *status, int32_t *iters, double *kkt_res,
+                           void *stream) {
   if (!h) return fail(nullptr, "cmpc_solve_batch: null handle");
   if (B < 0) return fail(h, "cmpc_solve_batch: negative batch");
   if (B == 0) return 0;
@@ -270,6 +277,7 @@ int cmpc_solve_batch(cmpc_handle *h, int32_t B, const double *params, const doub
   if (!guard.ok) return fail(h, "cmpc_solve_batch: cannot select the handle's device");
   cmpc::KArgs ka;
   ka.sp = h->spec; ka.B = B; ka.recs = params; ka.warm = warm_XU; ka.out = out_XU;
+  ka.state_in = state_in; ka.state_out = state_out;
   ka.status = status; ka.iters = iters; ka.kkt = kkt_res;
   ka.scratch = h->scratch; ka.scratch_stride = h->slab_doubles;
   ka.prof = h->prof;

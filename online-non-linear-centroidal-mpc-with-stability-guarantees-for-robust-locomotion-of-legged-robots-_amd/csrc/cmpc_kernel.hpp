@@ -54,12 +54,16 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 // hundreds of lane-derived index computations out of the stage / iteration loops (they were kept live
 // across the whole solve and spilled)
 #define CMPC_OPAQUE(x) asm volatile("" : "+v"(x))
+#define CMPC_OPAQUE_D(x) asm volatile("" : "+v"(x))
 // the lane id again from the execution mask (two instructions): where it is re-derived the old value need not stay
 // live -- or be spilled -- across the code in front (one wave per workgroup: lane id = thread id)
 #define CMPC_RELANE(x) do { (x) = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); } while (0)
 #endif
 #ifndef CMPC_RELANE
 #define CMPC_RELANE(x) do { } while (0)
+#endif
+#ifndef CMPC_OPAQUE_D
+#define CMPC_OPAQUE_D(x) do { } while (0)
 #endif
 
 // Optional phase timers (diagnostic build only, -DCMPC_PROFILE): cycles per phase summed over the
@@ -79,6 +83,8 @@ struct KArgs {
   int B;
   const double *recs;   // [B][nrec]
   const double *warm;   // [B][nsol] or null
+  const double *state_in;   // [B][nstate] or null: solver state of the previous tick (CMPC_NSTATE, include/cmpc.h)
+  double *state_out;        // [B][nstate] or null
   double *out;          // [B][nsol]
   int32_t *status;
   int32_t *iters;
@@ -106,6 +112,9 @@ constexpr int POLISH_ITERS = 1;
 // barrier schedule (see the oracle)
 constexpr double MU_INIT = 100.0;
 constexpr double MU_FACTOR = 0.1;
+// warm start of the interior point method: the solver state is the iterate at the last barrier value >= MU_WARM
+// (see the oracle for the choice of the level)
+constexpr double MU_WARM = 1e-7;
 
 #ifndef CMPC_NO_DEVICE_CODE
 #include "cmpc_lds_asm.hpp"
@@ -208,6 +217,14 @@ template <int NV> struct Dims {
   static constexpr int gL1 = gG + NI;         // l = gL + mu*gL1,  p = gPV + mu*gPV1
   static constexpr int gPV1 = gL1 + NU;
   static constexpr int STAGE = ((gPV1 + NXA + 7) / 8) * 8;
+  // solver state of one instance (CMPC_NSTATE): [XU | lam (N+1) x NXA | s (N+1) x NI | z (N+1) x NI | mu, 7 spare |
+  // contact flags of the N+1 nodes, left then right]
+  static constexpr int state_lam(int N) { return CMPC_NSOL(N, NV); }
+  static constexpr int state_s(int N) { return state_lam(N) + (N + 1) * NXA; }
+  static constexpr int state_z(int N) { return state_s(N) + (N + 1) * NI; }
+  static constexpr int state_mu(int N) { return state_z(N) + (N + 1) * NI; }
+  static constexpr int state_fl(int N) { return state_mu(N) + 8; }
+  static_assert(state_fl(20) + 2 * 21 == CMPC_NSTATE(20, NV), "layout of include/cmpc.h");
   // iterate arrays follow the (N+1) stage blocks
   static size_t scratch_doubles(int N) {
     size_t n = (size_t)(N + 1) * STAGE;
@@ -249,6 +266,7 @@ template <int NV> struct Solver {
   int lr[NH][6];
   double lg[NH][6];
   double piv_min = PIV_MIN;  // pivot acceptance threshold of the current sweep
+  GArr st_in{nullptr};       // solver state resumed from (null: cold rule for slacks / multipliers)
   long long tprof[28] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 
   CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
@@ -1204,8 +1222,12 @@ template <int NV> struct Solver {
         const double g = L(D::oGK + r);
         double s = L(D::oSK + r), z = L(D::oZK + r);
         if (init) {
-          s = act ? fmax(-g, 1e-2) : 1.0;
-          z = act ? mu / s : 0.0;
+          // rows carried over from the solver state; the cold rule for the rest (also: rows a contact switch has
+          // just activated)
+          // (initial_point left the state's slacks and multipliers in the iterate arrays, zeros on a cold start)
+          const bool carry = act && s > 0.0 && z > 0.0;
+          s = carry ? s : (act ? fmax(-g, fmin(1e-2, sqrt(mu))) : 1.0);
+          z = carry ? z : (act ? mu / s : 0.0);
           L(D::oZK + r) = z;
           gsl[k * NI + r] = s; gz[k * NI + r] = z;
         }
@@ -1559,25 +1581,48 @@ template <int NV> struct Solver {
   }
 
   // Initial point: warm start or hover forces; x_0 from the record; carried f_z states.
-  CMPC_DEV void initial_point(const double *warm_) {
-    const GArr warm{const_cast<double *>(warm_)};
-    const bool has_warm = warm_ != nullptr;
+  // warm_: primal start (the previous solution, or the XU block of the solver state when resuming); prox_: centre
+  // of the proximal term (the previous solution; null = 0); resume: dynamics multipliers from the solver state
+  CMPC_DEV void initial_point(const double *warm_, const double *prox_, bool resume) {
+    const GArr warm{const_cast<double *>(warm_)}, prox{const_cast<double *>(prox_)};
+    const bool has_warm = warm_ != nullptr, has_prox = prox_ != nullptr;
     const double m = rec[20];
+    // Source stage of every stage (see the oracle): stage k resumes from the state's stage k, or from its stage k + 1
+    // where a contact switch has moved one stage closer since the state was written.  Table in LDS (M is free here).
+    double *srct = &L(D::oM);
+    for (int k = lane; k <= N; k += 64) {
+      int src = k;
+      if (resume) {
+        const double gl = rec[(k < N) ? 24 + 19 * k + 17 : 22], gr = rec[(k < N) ? 24 + 19 * k + 18 : 23];
+        const int kn = (k < N) ? k + 1 : N;
+        const bool same = gl == st_in[D::state_fl(N) + k] && gr == st_in[D::state_fl(N) + N + 1 + k];
+        const bool next = k < N && gl == st_in[D::state_fl(N) + kn] && gr == st_in[D::state_fl(N) + N + 1 + kn];
+        if (!same && next) src = k + 1;
+      }
+      srct[k] = (double)src;
+    }
+    CMPC_SYNC();
     for (int e = lane; e < (N + 1) * NXA; e += 64) {
-      const int k = e / NXA, i = e % NXA;
+      const int k = e / NXA, i = e % NXA, ks = (int)srct[k];
       double v = 0.0;
-      if (i < CMPC_NX) v = (has_warm && k >= 1) ? warm[k * CMPC_NX + i] : rec[i];
-      gx[e] = v; glam[e] = 0.0;
+      if (i < CMPC_NX) v = (has_warm && k >= 1) ? warm[ks * CMPC_NX + i] : rec[i];
+      gx[e] = v; glam[e] = resume ? st_in[D::state_lam(N) + ks * NXA + i] : 0.0;
     }
     for (int e = lane; e < N * NU; e += 64) {
-      const int k = e / NU, i = e % NU;
-      double v = 0.0, up = 0.0;
-      if (has_warm) { v = warm[CMPC_NX * (N + 1) + e]; up = v; }
+      const int k = e / NU, i = e % NU, ks = ((int)srct[k] < N) ? (int)srct[k] : N - 1;
+      double v = 0.0, up = has_prox ? prox[CMPC_NX * (N + 1) + e] : 0.0;
+      if (has_warm) { v = warm[CMPC_NX * (N + 1) + ks * NU + i]; }
       else if (i < 6 * NV && (i % 3) == 2) {
         const double gl = rec[24 + 19 * k + 17], gr = rec[24 + 19 * k + 18];
         v = m * sp.g / (NV * (gl + gr)) * (((i / 3) < NV) ? gl : gr);
       }
       gu[e] = v; gupx[e] = up;
+    }
+    // slacks / multipliers of the solver state (zeros = none: the first sweep creates them by the cold rule)
+    for (int e = lane; e < (N + 1) * NI; e += 64) {
+      const int k = e / NI, i = e % NI, ks = (int)srct[k];
+      gsl[e] = resume ? st_in[D::state_s(N) + ks * NI + i] : 0.0;
+      gz[e] = resume ? st_in[D::state_z(N) + ks * NI + i] : 0.0;
     }
     CMPC_SYNC_GLOBAL();
     for (int e = lane; e < N * NF; e += 64) {
@@ -1595,21 +1640,57 @@ template <int NV> struct Solver {
     for (int e = lane; e < N * NU; e += 64) out[CMPC_NX * (N + 1) + e] = gu[e];
   }
 
+  // Solver state for the next tick (CMPC_NSTATE, include/cmpc.h): the current iterate, labelled with its barrier value.
+  CMPC_DEV void write_state(double *state_out, double mu_level) {
+    const GArr so{state_out};
+    CMPC_SYNC_GLOBAL();                         // (first iteration: the slacks were written by the sweep's lane mapping)
+    write_solution(state_out);
+    for (int e = lane; e < (N + 1) * NXA; e += 64) so[D::state_lam(N) + e] = glam[e];
+    for (int e = lane; e < (N + 1) * NI; e += 64) { so[D::state_s(N) + e] = gsl[e]; so[D::state_z(N) + e] = gz[e]; }
+    for (int k = lane; k <= N; k += 64) {
+      so[D::state_fl(N) + k] = rec[(k < N) ? 24 + 19 * k + 17 : 22];
+      so[D::state_fl(N) + N + 1 + k] = rec[(k < N) ? 24 + 19 * k + 18 : 23];
+    }
+    if (lane == 0) so[D::state_mu(N)] = mu_level;
+    CMPC_SYNC();                                // (host emulation: every lane has read the flag the caller sets next)
+  }
+
   // ---------------------------------------------------------------------------------------
-  CMPC_DEV void solve(const double *warm, double *out, int32_t *status, int32_t *iters, double *kkt_out) {
+  CMPC_DEV void solve(const double *warm, const double *state_in, double *state_out, double *out, int32_t *status,
+                      int32_t *iters, double *kkt_out) {
     const double tol = sp.tol;
     const double x0n2 = 0.0;                    // |hw_0|^2 is read from the record header in LDS where it is used
-    double mu = MU_INIT, kkt = INFINITY;
-    int st = CMPC_MAX_ITER, it = 0, n_acc = 0, n_stall = 0, polish = -1, since_best = 0;
+    // closed-loop ticks: resume from the previous tick's central-path point (see the oracle, MU_WARM)
+    bool resume = false;
+    if (state_in) {
+      const double ms = GArr{const_cast<double *>(state_in)}[D::state_mu(N)];
+      resume = ms > 0.0 && ms < INFINITY;
+      if (resume) st_in = GArr{const_cast<double *>(state_in)};
+    }
+    int st = CMPC_MAX_ITER, it = 0, spent = 0;
+    double kkt = INFINITY;
+    // at most two attempts: a resumed solve that gets nowhere (the state was too far from this tick's problem) is
+    // followed by the plain one; the iterations of both are reported (see the oracle)
+    for (;;) {
+    if (state_out && lane == 0) GArr{state_out}[D::state_mu(N)] = 0.0;     // invalid until a snapshot is taken
+    double mu = resume ? st_in[D::state_mu(N)] : MU_INIT;
+    kkt = INFINITY; st = CMPC_MAX_ITER;
+    int n_acc = 0, n_stall = 0, polish = -1, since_best = 0;
     bool use_saved = false;
     // cold scalars of the outer loop live in LDS (every lane reads the same word; written by every lane with the
     // same value, fenced by the phases in between)
     double &reg_last = L(D::oCOLD + 0), &kkt_best = L(D::oCOLD + 1), &kkt_saved = L(D::oCOLD + 2);
-    reg_last = 0.0; kkt_best = INFINITY; kkt_saved = INFINITY;
-    const double acc_tol = fmax(sp.acc_tol, tol);
-    // every iterate the acceptable-level counter counts is also saved (see the oracle)
-    const double save_tol = fmax(acc_tol, ACC_FACTOR * tol);
-    initial_point(warm);
+    double &snapped = L(D::oCOLD + 3);          // 1 once the solver state of this solve has been written
+    {
+      double inf = INFINITY, zero = 0.0;        // (materialised here: hoisted out of the instance loop they were spilled)
+      CMPC_OPAQUE_D(inf); CMPC_OPAQUE_D(zero);
+      reg_last = zero; kkt_best = inf; kkt_saved = inf; snapped = zero;
+    }
+    // acceptable level; every iterate the acceptable-level counter counts is also saved (see the oracle).  Formed
+    // where they are used (two instructions) instead of being kept live across the solve.
+    auto acc_tol = [&]() { return fmax(sp.acc_tol, tol); };
+    auto save_tol = [&]() { return fmax(fmax(sp.acc_tol, tol), ACC_FACTOR * tol); };
+    initial_point(resume ? state_in : warm, warm, resume);
     CMPC_TICK_RESET();
     for (it = 0; it <= sp.max_iter; ++it) {
       double reg = 0.0;
@@ -1641,15 +1722,17 @@ template <int NV> struct Solver {
       }
       if (polish < 0) {
         // best acceptable iterate so far (see the oracle): whatever ends the run, it is what is returned
-        if (kkt <= save_tol && kkt < ks) { write_solution(out); ks = kkt; kkt_saved = kkt; }
+        if (kkt <= save_tol() && kkt < ks) { write_solution(out); ks = kkt; kkt_saved = kkt; }
         if (kkt <= tol) {
+          // (the tolerance was met from a level >= MU_WARM: same snapshot)
+          if (state_out && mu >= MU_WARM && snapped == 0.0) { write_state(state_out, mu); snapped = 1.0; }
           polish = POLISH_ITERS; mu = tol / 10;
         } else {
           n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
           if (n_acc >= ACC_ITERS) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; break; }
           if (mu <= tol / 10) {                  // at the final barrier value: progress watch
             if (kkt < 0.5 * kb) { kb = kkt; kkt_best = kkt; since_best = 0; } else ++since_best;
-            if (since_best >= NOPROG_ITERS && ks <= acc_tol) {
+            if (since_best >= NOPROG_ITERS && ks <= acc_tol()) {
               st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; break;
             }
           }
@@ -1658,15 +1741,19 @@ template <int NV> struct Solver {
       if (polish == 0) { st = CMPC_CONVERGED; break; }
       if (it == sp.max_iter || !(kkt < INFINITY) || n_stall >= STALL_ITERS) {
         if (polish >= 0) st = CMPC_CONVERGED;                   // (cap reached inside the polish)
-        else if (ks <= acc_tol) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; }
+        else if (ks <= acc_tol()) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; }
         else st = (it == sp.max_iter) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
         break;
       }
       if (reg > 0) reg_last = reg;
       if (polish > 0) --polish;
-      else
+      else if (!(resume && it == 0)) {          // (a resumed solve re-centres at the state's barrier value first: see the oracle)
+        const double mu_before = mu;
         while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
           mu = fmax(tol / 10, fmin(MU_FACTOR * mu, mu * sqrt(mu)));
+        // this iterate solves the barrier problem at mu_before: the state the next tick resumes from
+        if (state_out && mu_before >= MU_WARM && mu < MU_WARM && snapped == 0.0) { write_state(state_out, mu_before); snapped = 1.0; }
+      }
       double ap, ad;
       vector_sweeps(mu, mu - mu_sweep, ap, ad);
       CMPC_TICK(6);
@@ -1675,7 +1762,11 @@ template <int NV> struct Solver {
       CMPC_TICK(7);
     }
     if (!use_saved) write_solution(out);
-    if (lane == 0) { *status = st; *iters = it; *kkt_out = kkt; }
+    if (!(resume && (st == CMPC_MAX_ITER || st == CMPC_NUMERICAL))) break;
+    spent += it; resume = false;
+    CMPC_SYNC_GLOBAL();
+    }
+    if (lane == 0) { *status = st; *iters = it + spent; *kkt_out = kkt; }
 #if defined(CMPC_PROFILE) && !defined(CMPC_HOST_EMU)
     if (lane == 0 && ka.prof)
       for (int i = 0; i < 28; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);

@@ -62,6 +62,11 @@ class ProblemSpec:
     def nsol(self):
         return NX * (self.N + 1) + self.nu * self.N
 
+    @property
+    def nstate(self):
+        """Doubles of the solver state carried between closed-loop ticks (CMPC_NSTATE, include/cmpc.h)."""
+        return self.nsol + (self.N + 1) * ((NX + 2 * self.nv) + 2 * (15 + 10 * self.nv) + 2) + 8
+
     def vertices(self):
         L, W = self.foot_length / 2, self.foot_width / 2
         corners = [[L, W, 0.], [L, -W, 0.], [-L, -W, 0.], [-L, W, 0.]]

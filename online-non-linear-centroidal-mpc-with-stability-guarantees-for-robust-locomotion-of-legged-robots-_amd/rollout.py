@@ -33,6 +33,8 @@ class BatchedRollout:
         self.state[:, 15] = torch.as_tensor(mu, dtype=f64, device=dev)
         self.t = torch.zeros(B, dtype=torch.int32, device=dev)
         self.warm = None
+        # solver states of the previous / this tick (cmpc_solve_batch_state), swapped every tick
+        self._state = [self.solver.new_state(B), self.solver.new_state(B)]
         self.alive = torch.ones(B, dtype=torch.bool, device=dev)
         # per-instance plans and the shared schedule (:656-675)
         self.update_contact = update_contact
@@ -68,6 +70,7 @@ class BatchedRollout:
         self.state[:, 9:12] = 0.0 if theta_hat is None else torch.as_tensor(theta_hat, dtype=f64, device=dev)
         self.state[:, 12:14] = 0.0
         self.warm = None
+        self._state[0].zero_()
         self.alive[:] = True
         self.flag[:] = False
         self.plan_pos = torch.from_numpy(self.scene.plan_pos).to(dev).repeat(self.B, 1, 1).contiguous()
@@ -77,8 +80,10 @@ class BatchedRollout:
         sp, N = self.spec, self.spec.N
         rec = self.builder.build(sp, self.t, self.state, rate=self.rate,
                                  plan_pos=self.plan_pos if self.update_contact else None)
-        XU, status, iters, kkt = self.solver.solve(rec, warm=self.warm)
+        s_in, s_out = self._state
+        XU, status, iters, kkt = self.solver.solve(rec, warm=self.warm, state=s_in, state_out=s_out)
         ok = usable(status) & self.alive
+        self._state = [s_out, s_in]              # (an instance whose solve failed stops for good, see `alive`)
         x1 = XU[:, 20:40]
         u0 = XU[:, 20 * (N + 1):20 * (N + 1) + sp.nu]
         self.last_records, self.last_XU, self.last_status, self.last_iters = rec, XU, status, iters

@@ -60,12 +60,14 @@ class BatchedCentroidalMPC:
     def workspace_bytes(self, B):
         return self._lib.cmpc_workspace_bytes(ctypes.byref(self._cspec), B)
 
-    def solve(self, records, warm=None, out=None):
+    def solve(self, records, warm=None, out=None, state=None, state_out=None):
         """records (B, nrec) fp64 on this GPU -> (XU (B, nsol), status, iters, kkt), all on the GPU.
 
         Asynchronous on torch's current stream.  ``warm`` (B, nsol) is the previous solution
         (initial guess and proximal centre), the batched form of ``opt.set_initial``
-        (code/centroidal_mpc_vertices.py:630-631).
+        (code/centroidal_mpc_vertices.py:630-631).  Closed-loop ticks additionally hand the solver state over:
+        ``state`` (B, nstate) = the previous tick's ``state_out`` (``new_state()`` for the first tick), and this
+        tick's state is written to ``state_out`` (a different tensor): ``cmpc_solve_batch_state``.
         """
         sp = self.spec
         if not (records.is_cuda and records.dtype == torch.float64 and records.is_contiguous()):
@@ -79,6 +81,12 @@ class BatchedCentroidalMPC:
             if not (warm.is_cuda and warm.dtype == torch.float64 and warm.is_contiguous()
                     and tuple(warm.shape) == (B, sp.nsol) and warm.device == self.device):
                 raise ValueError(f"warm must be a contiguous fp64 CUDA tensor of shape (B, {sp.nsol})")
+        for name, t in (("state", state), ("state_out", state_out)):
+            if t is not None and not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+                                      and tuple(t.shape) == (B, sp.nstate) and t.device == self.device):
+                raise ValueError(f"{name} must be a contiguous fp64 CUDA tensor of shape (B, {sp.nstate})")
+        if state is not None and state_out is not None and state.data_ptr() == state_out.data_ptr():
+            raise ValueError("state and state_out must be different tensors")
         if out is None:
             out = torch.empty((B, sp.nsol), dtype=torch.float64, device=records.device)
         status = torch.empty(B, dtype=torch.int32, device=records.device)
@@ -87,13 +95,20 @@ class BatchedCentroidalMPC:
         if B == 0:
             return out, status, iters, kkt
         stream = torch.cuda.current_stream(records.device).cuda_stream
-        rc = self._lib.cmpc_solve_batch(self._h, B, records.data_ptr(),
-                                        warm.data_ptr() if warm is not None else None,
-                                        out.data_ptr(), status.data_ptr(), iters.data_ptr(), kkt.data_ptr(),
-                                        ctypes.c_void_p(stream))
+        rc = self._lib.cmpc_solve_batch_state(self._h, B, records.data_ptr(),
+                                              warm.data_ptr() if warm is not None else None,
+                                              state.data_ptr() if state is not None else None,
+                                              out.data_ptr(),
+                                              state_out.data_ptr() if state_out is not None else None,
+                                              status.data_ptr(), iters.data_ptr(), kkt.data_ptr(),
+                                              ctypes.c_void_p(stream))
         if rc != 0:
             raise RuntimeError("cmpc_solve_batch failed: " + self._lib.cmpc_last_error(self._h).decode())
         return out, status, iters, kkt
+
+    def new_state(self, B):
+        """An empty solver state for B instances (barrier word 0 = "no state": the first tick starts cold)."""
+        return torch.zeros((B, self.spec.nstate), dtype=torch.float64, device=self.device)
 
     def last_kernel_ms(self):
         """Duration of the last solve's kernel (HIP events on the launch stream); synchronises."""

@@ -66,6 +66,18 @@
 #ifndef TAU_MIN                  /* fraction to the boundary */
 #define TAU_MIN 0.99
 #endif
+/* Warm start of the interior point method (closed-loop ticks): the iterate that solved the barrier problem at the
+ * last barrier value >= MU_WARM is kept as the solver state -- primal, dynamics multipliers, slacks and inequality
+ * multipliers, a point ON the central path of this tick's problem -- and the next tick's solve resumes from it at
+ * that barrier value instead of restarting at MU_INIT from the (boundary) solution.  See DESIGN.md section 4.
+ * Level: measured on the flat-ground walk (N = 10, 1900 ticks, tools/warm_walk.py), mean / median iterations and
+ * ticks ending "acceptable": primal warm start only 17.7 / 16 / 5; MU_WARM 1e-2: 12.9 / 11 / 10; 1e-5 (level 3.2e-5):
+ * 10.4 / 8 / 24; 1e-7 (level 1.8e-7, the last one before the final barrier value): 10.0 / 7 / 1.  From a level mu the
+ * complementarity products of weakly active rows shrink by at most 4x per Newton step (the ds*dz term), so the tail
+ * costs log4(mu / 1e-9) iterations whatever the schedule: the lowest interior level wins. */
+#ifndef MU_WARM
+#define MU_WARM 1e-7
+#endif
 
 /* inequality row slots of one stage */
 enum { R_LYAP = 0, R_CZ = 1, R_HWC = 2, R_BOX = 3, R_FRIC = 15 };
@@ -580,15 +592,16 @@ static void riccati_forward(const prob_t *P, work_t *W) {
 
 typedef struct { int iters, status; double kkt, mu, reg_last; int n_reg; } stats_t;
 
-static void initial_point(const prob_t *P, work_t *W, const double *warm) {
+static void initial_point(const prob_t *P, work_t *W, const double *warm, const int *src) {
   const int N = P->N, nx = P->nx, nu = P->nu, nv = P->nv;
   memset(W->x, 0, sizeof(double) * (N + 1) * nx);
   memset(W->u, 0, sizeof(double) * (N + 1) * nu);
   memset(W->uprox, 0, sizeof(double) * (N + 1) * nu);
   if (warm) {
-    for (int k = 0; k <= N; ++k) memcpy(W->x + (size_t)k * nx, warm + (size_t)k * CMPC_NX, sizeof(double) * CMPC_NX);
+    for (int k = 0; k <= N; ++k) memcpy(W->x + (size_t)k * nx, warm + (size_t)(src ? src[k] : k) * CMPC_NX, sizeof(double) * CMPC_NX);
     for (int k = 0; k < N; ++k) {
-      memcpy(W->u + (size_t)k * nu, warm + (size_t)CMPC_NX * (N + 1) + (size_t)k * nu, sizeof(double) * nu);
+      const int ks = src ? (src[k] < N ? src[k] : N - 1) : k;
+      memcpy(W->u + (size_t)k * nu, warm + (size_t)CMPC_NX * (N + 1) + (size_t)ks * nu, sizeof(double) * nu);
       memcpy(W->uprox + (size_t)k * nu, W->u + (size_t)k * nu, sizeof(double) * nu);
     }
   } else {
@@ -617,25 +630,61 @@ static void write_solution(const prob_t *P, const work_t *W, double *out) {
 
 /* One interior-point solve.  out: X then U (reference layout). */
 static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm, double *out,
-                      stats_t *st, int verbose, double *full) {
+                      stats_t *st, int verbose, double *full, const double *state_in, double *state_out) {
   prob_t Pb; prob_init(&Pb, sp, rec);
   const prob_t *P = &Pb;
   const int N = P->N, nx = P->nx, nu = P->nu, nz = P->nz, ni = P->ni;
   work_t *W = work_alloc(P);
-  initial_point(P, W, warm);
+  /* solver state (CMPC_NSTATE doubles): [XU of the snapshot | lam (N+1) x nx | s (N+1) x ni | z (N+1) x ni | mu, 7 spare] */
+  const size_t nsol_ = CMPC_NSOL(N, P->nv), o_lam = nsol_, o_s = o_lam + (size_t)(N + 1) * nx,
+               o_z = o_s + (size_t)(N + 1) * ni, o_mu = o_z + (size_t)(N + 1) * ni;
+  const int resume = state_in && state_in[o_mu] > 0.0 && isfinite(state_in[o_mu]);
+  /* The horizon moves by one stage per tick, but the stage INDEX carries structure of its own (contraction row at
+   * node 1, height weight e^{-i}): resuming stage k from the old stage k (unshifted, as the reference's set_initial,
+   * :630-631) measured 12.6 iterations per tick on the walk against 15.5 for the shifted state. */
+  /* Stage k resumes from the state's stage k -- unless a contact switch has moved: where the flags of stage k no
+   * longer match the state's stage k but do match its stage k + 1 (the switch sits one stage earlier than a tick
+   * ago), that stage is taken instead. */
+  const size_t o_fl = o_mu + 8;
+  int src[CMPC_MAX_N + 1];
+  for (int k = 0; k <= N; ++k) {
+    src[k] = k;
+    if (resume) {
+      const double gl = gam(P, k, 0), gr = gam(P, k, 1);
+      const int same = gl == state_in[o_fl + k] && gr == state_in[o_fl + N + 1 + k];
+      const int next = k < N && gl == state_in[o_fl + k + 1] && gr == state_in[o_fl + N + 1 + k + 1];
+      if (!same && next) src[k] = k + 1;
+    }
+  }
+  initial_point(P, W, resume ? state_in : warm, resume ? src : NULL);
+  if (resume) {                              /* the proximal centre stays the caller's warm_XU (or 0) */
+    memset(W->uprox, 0, sizeof(double) * (N + 1) * nu);
+    if (warm) for (int k = 0; k < N; ++k)
+      memcpy(W->uprox + (size_t)k * nu, warm + (size_t)CMPC_NX * (N + 1) + (size_t)k * nu, sizeof(double) * nu);
+  }
+  if (state_out) state_out[o_mu] = 0.0;      /* invalid until a snapshot is taken */
   const double x0n2 = rec[6] * rec[6] + rec[7] * rec[7] + rec[8] * rec[8];
-  double mu = MU_INIT, reg_last = 0.0;
+  double mu = resume ? state_in[o_mu] : MU_INIT, reg_last = 0.0;
   const double tol = sp->tol;
   /* slacks / multipliers */
   for (int k = 0; k <= N; ++k) {
     stage_ineq(P, k, W->x + (size_t)k * nx, W->u + (size_t)k * nu, x0n2, W->g + (size_t)k * ni,
                W->act + (size_t)k * ni, NULL, NULL, NULL);
     for (int i = 0; i < ni; ++i) {
-      double gi = W->g[(size_t)k * ni + i];
-      W->s[(size_t)k * ni + i] = W->act[(size_t)k * ni + i] ? fmax(-gi, 1e-2) : 1.0;
-      W->z[(size_t)k * ni + i] = W->act[(size_t)k * ni + i] ? mu / W->s[(size_t)k * ni + i] : 0.0;
+      const size_t e = (size_t)k * ni + i, es = (size_t)src[k] * ni + i;
+      double gi = W->g[e];
+      const double s0 = resume ? state_in[o_s + es] : 0.0, z0 = resume ? state_in[o_z + es] : 0.0;
+      if (resume && W->act[e] && s0 > 0.0 && z0 > 0.0) {     /* row carried over from the snapshot */
+        W->s[e] = s0; W->z[e] = z0;
+      } else {                                                  /* cold rule (also: rows a contact switch has just activated) */
+        W->s[e] = W->act[e] ? fmax(-gi, fmin(1e-2, sqrt(mu))) : 1.0;
+        W->z[e] = W->act[e] ? mu / W->s[e] : 0.0;
+      }
     }
   }
+  if (resume) for (int k = 0; k <= N; ++k)
+    memcpy(W->lam + (size_t)k * nx, state_in + o_lam + (size_t)src[k] * nx, sizeof(double) * nx);
+  int snapped = 0;
   st->status = CMPC_MAX_ITER; st->n_reg = 0;
   int it, n_acc = 0, n_stall = 0, polish = -1, since_best = 0, use_saved = 0;
   double kkt_best = INFINITY, kkt_saved = INFINITY;
@@ -649,7 +698,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
   for (it = 0; it <= sp->max_iter; ++it) {
     /* ---- linearise every stage ---- */
     double e_d = 0, e_p = 0, e_c = 0, e_cmu = 0, sum_mult = 0, fobj = 0;
-    int n_mult = 0;
+    int n_mult = 0, dbg_k = -1, dbg_j = -1;
     for (int k = 0; k <= N; ++k) {
       double *x = W->x + (size_t)k * nx, *u = W->u + (size_t)k * nu;
       double *H = W->H + (size_t)k * nz * nz, *ho = W->hobj + (size_t)k * nz;
@@ -673,6 +722,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
         if (k < N) for (int q = 0; q < nx; ++q) r += W->G[(size_t)k * nx * nz + q * nz + j] * W->lam[(size_t)(k + 1) * nx + q];
         if (j >= nu) r -= W->lam[(size_t)k * nx + (j - nu)];
         int is_var = (j < nu) ? (k < N) : (k >= 1);
+        if (is_var && fabs(r) > e_d) { dbg_k = k; dbg_j = j; }
         if (is_var) e_d = fmax(e_d, fabs(r));
       }
       for (int i = 0; i < ni; ++i) if (act[i]) {
@@ -685,7 +735,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     double sd = fmax(100.0, sum_mult / n_mult) / 100.0;
     kkt = fmax(fmax(e_d / sd, e_p), e_c / sd);
     if (verbose)
-      printf("it %3d f=%.8e d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e\n", it, fobj, e_d / sd, e_p, e_c / sd, mu, reg_last);
+      printf("it %3d f=%.8e d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e  (last step: ap %.3f ad %.3f; largest dual residual: stage %d column %d)\n", it, fobj, e_d / sd, e_p, e_c / sd, mu, reg_last, dbg_ap, dbg_ad, dbg_k, dbg_j);
     if (polish >= 0 && kkt > ACC_FACTOR * tol) {
       /* polishing lost ground (the step at the final barrier value needed an inertia correction): the
        * point that met the tolerance was written to `out` before the polish and is what is returned */
@@ -697,6 +747,15 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
        * ones; whatever ends the run, the best point seen is what is returned */
       if (kkt <= save_tol && kkt < kkt_saved) { write_solution(P, W, out); kkt_saved = kkt; }
       if (kkt <= tol) {
+        if (state_out && !snapped && mu >= MU_WARM) {   /* (the tolerance was met from a level >= MU_WARM: same snapshot) */
+          write_solution(P, W, state_out);
+          memcpy(state_out + o_lam, W->lam, sizeof(double) * (N + 1) * nx);
+          memcpy(state_out + o_s, W->s, sizeof(double) * (N + 1) * ni);
+          memcpy(state_out + o_z, W->z, sizeof(double) * (N + 1) * ni);
+          state_out[o_mu] = mu;
+          for (int k = 0; k <= N; ++k) { state_out[o_fl + k] = gam(P, k, 0); state_out[o_fl + N + 1 + k] = gam(P, k, 1); }
+          snapped = 1;
+        }
         polish = POLISH_ITERS; mu = tol / 10;
       } else {
         /* IPOPT-style acceptable level: ACC_ITERS consecutive iterates within ACC_FACTOR*tol */
@@ -718,9 +777,24 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
       break;
     }
     if (polish > 0) --polish;
-    else
+    else if (!(resume && it == 0)) {
+      /* (a resumed solve takes one Newton step at the state's barrier value first, whatever the error there: the
+       * state written below is then a central-path point of THIS tick's problem, not a copy of the one read --
+       * copies went stale and every other tick paid 18 iterations instead of 7) */
+      const double mu_before = mu;
       while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < KAPPA_EPS * mu)
         mu = fmax(tol / 10, fmin(MU_FACTOR * mu, (MU_POWER == 1.5) ? mu * sqrt(mu) : pow(mu, MU_POWER)));
+      if (state_out && !snapped && mu_before >= MU_WARM && mu < MU_WARM) {
+        /* this iterate solves the barrier problem at mu_before: the state the next tick resumes from */
+        write_solution(P, W, state_out);
+        memcpy(state_out + o_lam, W->lam, sizeof(double) * (N + 1) * nx);
+        memcpy(state_out + o_s, W->s, sizeof(double) * (N + 1) * ni);
+        memcpy(state_out + o_z, W->z, sizeof(double) * (N + 1) * ni);
+        state_out[o_mu] = mu_before;
+        for (int k = 0; k <= N; ++k) { state_out[o_fl + k] = gam(P, k, 0); state_out[o_fl + N + 1 + k] = gam(P, k, 1); }
+        snapped = 1;
+      }
+    }
     /* ---- barrier-augmented QP data ---- */
     for (int k = 0; k <= N; ++k) {
       double *H = W->H + (size_t)k * nz * nz, *h = W->h + (size_t)k * nz, *ho = W->hobj + (size_t)k * nz;
@@ -809,6 +883,13 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
   }
   st->iters = it; st->kkt = kkt; st->mu = mu; st->reg_last = reg_last;
   work_free(W);
+  if (resume && (st->status == CMPC_MAX_ITER || st->status == CMPC_NUMERICAL)) {
+    /* the resumed solve got nowhere (the state was too far from this tick's problem): start again the plain way;
+     * the iterations of both attempts are reported */
+    const int spent = st->iters;
+    solve_one(sp, rec, warm, out, st, verbose, full, NULL, state_out);
+    st->iters += spent;
+  }
 }
 
 /* ------------------------------------ exported API -------------------------------------- */
@@ -827,7 +908,7 @@ int cmpc_oracle_solve(const cmpc_spec *sp, const double *rec, const double *warm
                       int32_t *status, int32_t *iters, double *kkt, int verbose) {
   if (sp->N < 1 || sp->N > CMPC_MAX_N || (sp->nv != 4 && sp->nv != 8)) return 1;
   stats_t st;
-  solve_one(sp, rec, warm, out, &st, verbose, NULL);
+  solve_one(sp, rec, warm, out, &st, verbose, NULL, NULL, NULL);
   if (status) *status = st.status;
   if (iters) *iters = st.iters;
   if (kkt) *kkt = st.kkt;
@@ -844,7 +925,28 @@ int cmpc_oracle_solve_batch(const cmpc_spec *sp, int32_t B, const double *recs, 
 #endif
   for (int b = 0; b < B; ++b) {
     stats_t st;
-    solve_one(sp, recs + b * nrec, warm ? warm + b * nsol : NULL, out + b * nsol, &st, 0, NULL);
+    solve_one(sp, recs + b * nrec, warm ? warm + b * nsol : NULL, out + b * nsol, &st, 0, NULL, NULL, NULL);
+    if (status) status[b] = st.status;
+    if (iters) iters[b] = st.iters;
+    if (kkt) kkt[b] = st.kkt;
+  }
+  return 0;
+}
+
+/* Batch solve with solver states (closed-loop ticks): state_in / state_out [B][CMPC_NSTATE(N, nv)], either may be NULL. */
+int cmpc_oracle_solve_batch_state(const cmpc_spec *sp, int32_t B, const double *recs, const double *warm,
+                                  const double *state_in, double *out, double *state_out, int32_t *status,
+                                  int32_t *iters, double *kkt, int nthreads, int verbose) {
+  if (sp->N < 1 || sp->N > CMPC_MAX_N || (sp->nv != 4 && sp->nv != 8)) return 1;
+  const size_t nrec = CMPC_NREC(sp->N), nsol = CMPC_NSOL(sp->N, sp->nv), nst = CMPC_NSTATE(sp->N, sp->nv);
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int b = 0; b < B; ++b) {
+    stats_t st;
+    solve_one(sp, recs + b * nrec, warm ? warm + b * nsol : NULL, out + b * nsol, &st, verbose, NULL,
+              state_in ? state_in + b * nst : NULL, state_out ? state_out + b * nst : NULL);
     if (status) status[b] = st.status;
     if (iters) iters[b] = st.iters;
     if (kkt) kkt[b] = st.kkt;
@@ -855,7 +957,7 @@ int cmpc_oracle_solve_batch(const cmpc_spec *sp, int32_t B, const double *recs, 
 /* Diagnostic: solve and also return the full primal-dual iterate (x, lam, s, z). */
 int cmpc_oracle_solve_full(const cmpc_spec *sp, const double *rec, const double *warm, double *out, double *full) {
   stats_t st;
-  solve_one(sp, rec, warm, out, &st, 0, full);
+  solve_one(sp, rec, warm, out, &st, 0, full, NULL, NULL);
   return st.status;
 }
 

@@ -83,6 +83,24 @@ def solve_batch(spec, recs, warm=None, nthreads=0):
     return out, st, it, kkt
 
 
+def nstate(s):
+    return nsol(s) + (s.N + 1) * ((20 + 2 * s.nv) + 2 * (15 + 10 * s.nv) + 2) + 8
+
+
+def solve_batch_state(spec, recs, warm=None, state=None, nthreads=0, verbose=0):
+    """Closed-loop form: (out, state_out, status, iters, kkt); `state` = the previous tick's state_out (or None)."""
+    recs = np.ascontiguousarray(np.atleast_2d(recs), dtype=np.float64)
+    B = recs.shape[0]
+    warm = None if warm is None else np.ascontiguousarray(warm, dtype=np.float64)
+    state = None if state is None else np.ascontiguousarray(state, dtype=np.float64)
+    out, state_out = np.zeros((B, nsol(spec))), np.zeros((B, nstate(spec)))
+    st, it, kkt = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
+    rc = lib().cmpc_oracle_solve_batch_state(ctypes.byref(spec), B, _p(recs), _p(warm), _p(state), _p(out), _p(state_out),
+                                             _p(st), _p(it), _p(kkt), int(nthreads), int(verbose))
+    assert rc == 0
+    return out, state_out, st, it, kkt
+
+
 def evaluate(spec, rec, w, uprox=None):
     """(cost, defects (N,20), ineq ((N+1), ni), act) of the C restatement at a full primal point."""
     N, ni = spec.N, 15 + 10 * spec.nv

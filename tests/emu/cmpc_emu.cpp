@@ -78,24 +78,34 @@ static inline cmpc_v4d emu_mfma(double a, double b, cmpc_v4d c) {
 template <int NV>
 static void run_batch(const cmpc::KArgs &ka, double *lds) {
   const cmpc_spec &sp = ka.sp;
-  const size_t nrec = CMPC_NREC(sp.N), nsol = CMPC_NSOL(sp.N, NV);
+  const size_t nrec = CMPC_NREC(sp.N), nsol = CMPC_NSOL(sp.N, NV), nstate = CMPC_NSTATE(sp.N, NV);
   for (int p = 0; p < ka.B; ++p) {
     std::vector<std::thread> th;
     for (int l = 0; l < 64; ++l)
       th.emplace_back([&, l]() {
         emu_lane_id = l;
         cmpc::Solver<NV> s(ka, lds, ka.scratch, ka.recs + p * nrec);
-        s.solve(ka.warm ? ka.warm + p * nsol : nullptr, ka.out + p * nsol, ka.status + p, ka.iters + p, ka.kkt + p);
+        s.solve(ka.warm ? ka.warm + p * nsol : nullptr, ka.state_in ? ka.state_in + p * nstate : nullptr,
+                ka.state_out ? ka.state_out + p * nstate : nullptr, ka.out + p * nsol, ka.status + p, ka.iters + p, ka.kkt + p);
       });
     for (auto &t : th) t.join();
   }
 }
 
+extern "C" int cmpc_emu_solve_batch_state(const cmpc_spec *sp, int32_t B, const double *recs, const double *warm,
+                                          const double *state_in, double *out, double *state_out, int32_t *status,
+                                          int32_t *iters, double *kkt);
 extern "C" int cmpc_emu_solve_batch(const cmpc_spec *sp, int32_t B, const double *recs, const double *warm,
                                     double *out, int32_t *status, int32_t *iters, double *kkt) {
+  return cmpc_emu_solve_batch_state(sp, B, recs, warm, nullptr, out, nullptr, status, iters, kkt);
+}
+extern "C" int cmpc_emu_solve_batch_state(const cmpc_spec *sp, int32_t B, const double *recs, const double *warm,
+                                          const double *state_in, double *out, double *state_out, int32_t *status,
+                                          int32_t *iters, double *kkt) {
   if (sp->N < 1 || sp->N > CMPC_MAX_N || (sp->nv != 4 && sp->nv != 8)) return 1;
   cmpc::KArgs ka;
   ka.sp = *sp; ka.B = B; ka.recs = recs; ka.warm = warm; ka.out = out;
+  ka.state_in = state_in; ka.state_out = state_out;
   ka.status = status; ka.iters = iters; ka.kkt = kkt; ka.prof = nullptr;
   const size_t nd = (sp->nv == 4) ? cmpc::Dims<4>::scratch_doubles(sp->N) : cmpc::Dims<8>::scratch_doubles(sp->N);
   const size_t nl = (sp->nv == 4) ? cmpc::Dims<4>::LDS_DOUBLES : cmpc::Dims<8>::LDS_DOUBLES;

@@ -41,20 +41,39 @@ CASES = {
 }
 
 
+# Round 3: the build-defined generalisations of BASELINE configs 4 and 5 (per-instance mass and friction coefficient,
+# a push on the initial velocity / angular momentum, 8-vertex contact patches).  name: (N, tick, payload gains, what,
+# extras) with extras = mass scale, mu, velocity push (m/s), angular-momentum push (kg m^2/s), vertices per foot.
+CASES_X = {
+    "N10_c4_m080_mu03_ss": (10, 230, False, "config 4: mass x0.8, mu 0.3, pushed, single support",
+                             dict(mass=0.8, mu=0.3, dv=(0.06, -0.04, 0.0), dhw=(0.3, -0.5, 0.1))),
+    "N10_c4_m120_mu09_late_ss": (10, 262, False, "config 4: mass x1.2, mu 0.9, pushed, late single support + touch-down",
+                                  dict(mass=1.2, mu=0.9, dv=(-0.05, 0.08, 0.0), dhw=(-0.6, 0.4, -0.2))),
+    "N10_c4_m090_mu03_ds": (10, 120, False, "config 4: mass x0.9, mu 0.3, pushed, double support",
+                             dict(mass=0.9, mu=0.3, dv=(0.10, 0.05, 0.0), dhw=(0.8, 0.8, 0.0))),
+    "N10_c4_m110_mu09_liftoff": (10, 292, False, "config 4: mass x1.1, mu 0.9, pushed, lift-off inside the horizon",
+                                  dict(mass=1.1, mu=0.9, dv=(0.0, -0.10, 0.0), dhw=(0.5, 0.0, 0.3))),
+    "N10_nv8_t120_ds": (10, 120, False, "config 5: 8 vertices per foot, double support", dict(nv=8)),
+    "N10_nv8_t240_mid_ss": (10, 240, False, "config 5: 8 vertices per foot, mid single support", dict(nv=8)),
+    "N10_nv8_c4_m085_mu04_late_ss": (10, 262, False, "configs 4 + 5: 8 vertices, mass x0.85, mu 0.4, pushed, late single support",
+                                      dict(nv=8, mass=0.85, mu=0.4, dv=(0.04, 0.04, 0.0), dhw=(0.2, -0.3, 0.0))),
+}
+CASES.update(CASES_X)
+
 LINE_SEARCH_CASES = ("N10_t120_ds", "N10_t210_early_ss", "N10_t262_late_ss")
 
 
-def record(N, t, payload):
-    spec = ProblemSpec(N=N)
+def record(N, t, payload, mass=1.0, mu=0.5, dv=(0.0, 0.0, 0.0), dhw=(0.0, 0.0, 0.0), nv=4):
+    spec = ProblemSpec(N=N, nv=nv)
     if payload:
         spec.k1, spec.k2 = 7.0, 1.0
     sc = wl.scene()
     com, dcom = sc.nominal_state(np.array([t]))
     com = com + np.array([[0.004, -0.003, 0.001]])
-    dcom = dcom + np.array([[0.01, -0.02, 0.0]])
+    dcom = dcom + np.array([[0.01, -0.02, 0.0]]) + np.asarray(dv)[None]
     theta = np.array([[2.0, -3.0, 1.0]]) if payload else np.zeros((1, 3))
-    rec = sc.build_records(spec, np.array([t]), com, dcom, HW[t][None], theta, np.zeros(1), np.zeros(1),
-                           np.full(1, wl.HRP4_MASS), np.full(1, 0.5))[0]
+    rec = sc.build_records(spec, np.array([t]), com, dcom, HW[t][None] + np.asarray(dhw)[None], theta, np.zeros(1), np.zeros(1),
+                           np.full(1, wl.HRP4_MASS * mass), np.full(1, mu))[0]
     return spec, rec
 
 
@@ -109,14 +128,16 @@ def main():
     torch.set_num_threads(int(os.environ.get("PIN_THREADS", "4")))
     names = sys.argv[1:] or list(CASES)
     for name in names:
-        N, t, payload, what = CASES[name]
-        spec, rec = record(N, t, payload)
-        ns = nlp.Spec(N=N, k1=spec.k1, k2=spec.k2)
+        N, t, payload, what = CASES[name][:4]
+        extras = dict(CASES[name][4]) if len(CASES[name]) > 4 else {}
+        tol = extras.pop("tol", 1e-9)
+        spec, rec = record(N, t, payload, **extras)
+        ns = nlp.Spec(N=N, nv=spec.nv, k1=spec.k1, k2=spec.k2)
         par = nlp.unpack_record(ns, rec)
         w0 = cold_start(ns, par)
-        out = {"record": rec, "N": N, "nv": 4, "k1": spec.k1, "k2": spec.k2, "tick": t, "what": what}
+        out = {"record": rec, "N": N, "nv": spec.nv, "k1": spec.k1, "k2": spec.k2, "tick": t, "what": what}
         t0 = time.time()
-        r = ipm_dense.solve(ns, par, w0=w0, tol=1e-9, max_iter=120, linesearch=False)
+        r = ipm_dense.solve(ns, par, w0=w0, tol=tol, max_iter=120, linesearch=False)
         out.update(sol_ipm_dense=r["w"], ipm_dense_status=r["status"], ipm_dense_iters=r["iters"], ipm_dense_kkt=r["kkt"])
         print(f"{name}: ipm_dense (full Newton steps) status {r['status']} iters {r['iters']} kkt {r['kkt']:.2e} "
               f"{time.time() - t0:.0f} s", flush=True)

@@ -108,7 +108,7 @@ def test_independent_pins(gpu, oracle, path):
     restatement, scipy trust-constr): tests/test_independent_pins.py, tests/golden/make_independent_pins.py."""
     from test_independent_pins import check_against_pin
     pin = np.load(path)
-    spec = ProblemSpec(N=int(pin["N"]), nv=4, k1=float(pin["k1"]), k2=float(pin["k2"]), tol=1e-9, max_iter=200)
+    spec = ProblemSpec(N=int(pin["N"]), nv=int(pin["nv"]), k1=float(pin["k1"]), k2=float(pin["k2"]), tol=1e-9, max_iter=200)
     got, st, it, kkt = _solve(gpu, spec, pin["record"][None, :])
     assert st[0] in (0, 3) and kkt[0] < 1e-7
     cs = oracle_spec(oracle, spec)

@@ -2,7 +2,9 @@
 oracle and without the HIP solver (tests/golden/make_independent_pins.py: a dense full-space interior point on
 the literal torch restatement of the NLP with autograd derivatives, and scipy's trust-constr on the same
 restatement) for ticks of the flat-ground walk that cover double support, lift-off, early / mid / late single
-support and touch-down, nominal and payload gains, N = 10 and N = 20.  The C oracle must reproduce them here;
+support and touch-down, nominal and payload gains, N = 10 and N = 20, and (round 3) for the build-defined
+generalisations of BASELINE configs 4 and 5: per-instance mass (x0.8 ... x1.2) and friction coefficient (0.3 ... 0.9)
+with pushed initial velocity / angular momentum, and 8-vertex contact patches.  The C oracle must reproduce them here;
 the HIP solver reproduces them in tests/test_gpu_parity.py::test_independent_pins."""
 import glob
 import os
@@ -18,11 +20,18 @@ FILES = sorted(glob.glob(os.path.join(GOLD, "independent_pin_*.npz")))
 
 def check_against_pin(pin, sol, evaluate):
     """`sol`: a solver's answer for pin['record'];  evaluate(w) -> (cost, defects, ineq, act)."""
-    N = int(pin["N"])
+    N, nu = int(pin["N"]), 6 * int(pin["nv"]) + 8
     anchors = 0
+    # 8-vertex patches: the split of a foot's force over eight vertices is held by the 1e-4 proximal weight alone, so a
+    # point that meets the independent solver's 1e-9 tolerance can sit 1e-5 along that valley (measured on the mid
+    # single-support pin: 1.07e-5 in hw_x, objectives equal to 5e-12; a 1e-10 run of the dense solver hovered for 20
+    # minutes without meeting it).  Still a factor 3 inside the north-star tolerance, and the objective must agree.
+    lim = 1e-5 if int(pin["nv"]) == 4 else 3e-5
     if float(pin["ipm_dense_kkt"]) <= 1e-7:                     # dense interior point, full Newton steps (no safeguards:
         # it may hover just above its 1e-9 tolerance, or fail outright -- then the other solver anchors the case)
-        assert rel_inf(sol, pin["sol_ipm_dense"])[0] < 1e-5 and group_rel_inf(sol, pin["sol_ipm_dense"], N, 32)[0] < 1e-5
+        assert rel_inf(sol, pin["sol_ipm_dense"])[0] < lim and group_rel_inf(sol, pin["sol_ipm_dense"], N, nu)[0] < lim
+        f_s, f_d = evaluate(sol)[0], evaluate(pin["sol_ipm_dense"])[0]
+        assert abs(f_s - f_d) <= 1e-9 * abs(f_d)
         anchors += 1
     if "ipm_dense_ls_status" in pin.files and int(pin["ipm_dense_ls_status"]) == 0:   # same, l1 line search
         assert rel_inf(sol, pin["sol_ipm_dense_ls"])[0] < 1e-5
@@ -48,12 +57,18 @@ def test_pin_files_cover_the_walk():
     for phase in ("double support", "lift-off", "early single support", "late single support", "touch-down", "payload"):
         assert phase in whats
     assert sum(int(np.load(f)["N"]) == 20 for f in FILES) >= 2
+    # round 3: the build-defined generalisations (BASELINE configs 4 and 5) are anchored too
+    assert sum("config 4" in str(np.load(f)["what"]) or "configs 4" in str(np.load(f)["what"]) for f in FILES) >= 4
+    assert sum(int(np.load(f)["nv"]) == 8 for f in FILES) >= 2
+    masses = {round(float(np.load(f)["record"][20]), 3) for f in FILES}
+    mus = {round(float(np.load(f)["record"][21]), 3) for f in FILES}
+    assert len(masses) >= 4 and {0.3, 0.9} <= mus
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[16:-4] for f in FILES])
 def test_oracle_reproduces_independent_pins(oracle, path):
     pin = np.load(path)
-    cs = oracle.default_spec(N=int(pin["N"]), nv=4, tol=1e-9, max_iter=200, k1=float(pin["k1"]), k2=float(pin["k2"]))
+    cs = oracle.default_spec(N=int(pin["N"]), nv=int(pin["nv"]), tol=1e-9, max_iter=200, k1=float(pin["k1"]), k2=float(pin["k2"]))
     sol, st, it, kkt = oracle.solve(cs, pin["record"])
     assert st in (0, 3) and kkt < 1e-7
     check_against_pin(pin, sol, lambda w: oracle.evaluate(cs, pin["record"], w))
