@@ -16,11 +16,12 @@ def _newer(target, sources):
 
 def build_hip(force=False, verbose=False):
     src = os.path.join(PKG, "csrc", "cmpc_hip.hip")
-    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"),
-            os.path.join(ROOT, "include", "cmpc.h")]
+    wbc = os.path.join(PKG, "csrc", "wbc_qp.hip")          # batched whole-body QP (include/cmpc_wbc.h), same library
+    deps = [src, wbc, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"),
+            os.path.join(ROOT, "include", "cmpc.h"), os.path.join(ROOT, "include", "cmpc_wbc.h")]
     out = os.path.join(PKG, "libcmpc_amd.so")
     if force or _newer(out, deps):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out, src]
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out, src, wbc]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)

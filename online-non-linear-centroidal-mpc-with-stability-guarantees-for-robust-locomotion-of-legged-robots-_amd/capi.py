@@ -18,6 +18,8 @@ SYMBOLS = ("cmpc_default_spec", "cmpc_create", "cmpc_destroy", "cmpc_workspace_b
            "cmpc_solve_batch", "cmpc_solve_batch_state", "cmpc_last_kernel_ms", "cmpc_last_error", "cmpc_version",
            "cmpc_tables_create", "cmpc_tables_destroy", "cmpc_build_records",
            "cmpc_tables_set_plan_slots", "cmpc_build_records_planned")
+#: every symbol include/cmpc_wbc.h declares (batched whole-body QP, same library)
+WBC_SYMBOLS = ("cmpc_wbc_qp_solve_batch", "cmpc_wbc_last_error")
 
 _lib = None
 
@@ -59,6 +61,11 @@ def load():
     lib.cmpc_tables_set_plan_slots.restype = ctypes.c_int
     lib.cmpc_build_records_planned.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.cmpc_build_records_planned.restype = ctypes.c_int
+    f64 = ctypes.c_double
+    lib.cmpc_wbc_qp_solve_batch.argtypes = [ctypes.c_int, i32, vp, vp, vp, vp, vp, f64, f64, f64, i32, vp, vp, vp, vp, vp, vp]
+    lib.cmpc_wbc_qp_solve_batch.restype = ctypes.c_int
+    lib.cmpc_wbc_last_error.argtypes = []
+    lib.cmpc_wbc_last_error.restype = ctypes.c_char_p
     lib.cmpc_version.argtypes = []
     lib.cmpc_version.restype = ctypes.c_char_p
     _lib = lib

@@ -143,6 +143,29 @@ def test_batch_composition_does_not_change_results(gpu):
     assert np.array_equal(d, a[100:164])
 
 
+def test_batch_composition_eight_vertex_kernel_beyond_its_resident_grid(gpu, oracle):
+    """The same for cmpc_solve_kernel<8> (BASELINE config 5: N = 40, 8 vertices per foot) with more instances than
+    its 512 resident slots (2 workgroups per CU): ticket and slab reuse at NV = 8, which no test exercised in round 2.
+    Bitwise batch-composition independence, and a sample against the oracle."""
+    spec, rec = wl.make_workload("long_horizon", B=1152)
+    spec.max_iter = 150
+    assert spec.nv == 8 and spec.N == 40
+    a, st_a, it_a, kkt_a = _solve(gpu, spec, rec)
+    assert np.isin(st_a, (0, 3)).mean() > 0.95 and (st_a == 1).sum() == 0
+    perm = np.random.default_rng(1).permutation(rec.shape[0])
+    c, st_c, it_c, _ = _solve(gpu, spec, rec[perm])
+    assert np.array_equal(c, a[perm]) and np.array_equal(st_c, st_a[perm]) and np.array_equal(it_c, it_a[perm])
+    d, st_d, _, _ = _solve(gpu, spec, rec[1000:1040])        # alone (first use of their slabs) = as part of the big batch
+    assert np.array_equal(d, a[1000:1040])
+    idx = np.arange(1100, 1124)                                # instances drawn late from the queue: reused slabs
+    ref, st_ref, _, _ = oracle.solve_batch(oracle_spec(oracle, spec), rec[idx])
+    both = np.isin(st_a[idx], (0, 3)) & np.isin(st_ref, (0, 3))
+    assert both.mean() > 0.9
+    err = rel_inf(a[idx][both], ref[both])
+    med_all, _, _, share, _ = LEVELS["long"]                  # the parity levels of this problem class (above)
+    assert np.median(err) < med_all and (err < REL_TOL).mean() >= 1.0 - share - 0.05
+
+
 def test_two_handles_on_two_streams_overlap_without_interference(gpu):
     """bench.py alternates consecutive batches over two solver handles on two HIP streams (the straggler
     tail of one launch overlaps the next).  Handles share nothing: the overlapped results are bitwise the
