@@ -24,7 +24,8 @@ are counted as solves.  The same JSON line also carries
                 only: the drain of one launch -- its longest instance -- overlaps the next launch)
   warm_start    every instance re-solved from its own solution and solver state (cmpc_solve_batch_state: the
                 closed-loop entry point; the closed loop proper is tools/walk_demo.py)
-  batch_sweep   B in {1, 16, 256, 4096, 65536} on one GPU, one launch each (BASELINE metric range)
+  batch_sweep   B in {1, 16, 256, 4096, 65536} on one GPU (BASELINE metric range); 65536 repeated three times
+  wbc_qp        the batched whole-body inverse-dynamics QP at B = 65536
   roofline      HBM classification of SURVEY.md 8d: algorithmic bytes B_io per solve x solves per launch /
                 kernel time (HIP events on the launch stream, non-overlapped launch) vs 8 TB/s
   cpu_baseline  the C oracle (a port, not CasADi/IPOPT) on all host cores, bounded sample, rank 0, N=1
@@ -217,7 +218,7 @@ def main():
     st = full[:, -2].to(torch.int32)
     it = full[:, -1]
     frac = {name: float((st == code).double().mean().item())
-            for name, code in (("converged", 0), ("iteration_cap", 1), ("locally_infeasible", 2), ("acceptable", 3))}
+            for name, code in (("converged", 0), ("iteration_cap", 1), ("status_2", 2), ("acceptable", 3))}
     mean_iters = float(it.mean().item())
     rate_all = B_total * args.steps / elapsed
     value = rate_all * frac["converged"]
@@ -244,8 +245,9 @@ def main():
                                   f"{'strictly serial launches' if S == 1 else f'steps alternate over {S} HIP streams'}"},
         "outcome": dict(frac, usable_solves_per_s=rate_all * (frac["converged"] + frac["acceptable"]),
                         all_instances_per_s=rate_all,
-                        note="locally infeasible = step length collapsed; on this workload every such instance "
-                             "checked is certified infeasible by the convex first-stage problem "
+                        note="status_2 = no usable point (include/cmpc.h: step length collapsed, regularisation exhausted "
+                             "or non-finite iterate); on this workload every such instance checked is a locally infeasible "
+                             "draw, certified infeasible by a dual lower bound of the convex first-stage problem "
                              "(oracle/stage0_feasibility.py, tests/test_oracle.py)"),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
@@ -284,13 +286,49 @@ def main():
             d = torch.from_numpy(rs).to(device)
             if Bs > outs[0].shape[0]:
                 outs[0] = torch.empty((Bs, spec.nsol), dtype=torch.float64, device=device)
-            reps = 3 if Bs <= 4096 else 1
+            reps = 3
             els, fs = timed(1, reps, 1, records=d)
             cs_ = float((fs[:, -2] == 0).double().mean().item())
             sweep[str(Bs)] = {"ms_per_launch": els / reps * 1e3, "all_instances_per_s": Bs * reps / els,
                               "converged_solves_per_s": Bs * reps / els * cs_}
             del d
         result["batch_sweep"] = sweep
+
+    if world == 1 and not args.no_extras:
+        # --- the next row of the scope table: batched whole-body inverse-dynamics QP, B = 65536
+        from cmpc_amd import wbc
+        from oracle import wbc_qp_oracle as wq        # synthetic matrices only here; the oracle's solver is timed below
+        Bq, uniq = 65536, 1024
+        mats = [torch.from_numpy(np.ascontiguousarray(np.tile(a, (Bq // uniq,) + (1,) * (a.ndim - 1)))).to(device)
+                for a in wq.synthetic(uniq, seed=20250715)]
+        qp = wbc.BatchedInverseDynamicsQP(foot_size=0.1, mu=0.5, device=device)
+        qp.solve(*mats)
+        torch.cuda.synchronize(device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(3):
+            _, _, _, st_q, it_q = qp.solve(*mats)
+        ev1.record()
+        torch.cuda.synchronize(device)
+        ms_q = ev0.elapsed_time(ev1) / 3
+        bytes_q = 8 * (2 * 900 + 2 * 30 + 360 + 30 + 30 + 12) + 8       # Hq, M, Fq, h, Jc in; tau, qdd, f_c, status, iters out
+        result["wbc_qp"] = {"qps_per_s": Bq / (ms_q * 1e-3), "batch": Bq, "ms_per_launch": ms_q,
+                            "converged": float((st_q == 0).double().mean().item()),
+                            "mean_iterations": float(it_q.double().mean().item()),
+                            "algorithmic_bytes_per_qp": bytes_q,
+                            "hbm_frac": bytes_q * Bq / (ms_q * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "code/inverse_dynamics.py:92-134 for 65536 robots (1024 distinct synthetic instances, "
+                                    "30 dofs, double support), wbc_qp_kernel, KKT error <= 1e-9; latency bound like the MPC "
+                                    "kernel (one wave per QP, 48 serial pivots per Newton step)"}
+        if not args.no_cpu_baseline:
+            t0 = time.perf_counter()
+            nq = 0
+            Hs, Fs, Ms, hs, Js = wq.synthetic(64, seed=20250715)
+            while time.perf_counter() - t0 < 5.0 and nq < 64:
+                wq.solve(Hs[nq], Fs[nq], Ms[nq], hs[nq], Js[nq], 0.05, 0.5)
+                nq += 1
+            result["wbc_qp"]["cpu_oracle_qps_per_s_one_core"] = nq / (time.perf_counter() - t0)
+        del mats
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle_lib as ol

@@ -36,7 +36,7 @@ def build_hip_profile(force=False):
     out = os.path.join(ROOT, "tools", "libcmpc_amd_prof.so")
     if force or _newer(out, deps):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-DCMPC_PROFILE", "-o", out, src])
+                               "-DCMPC_PROFILE", "-o", out, src, os.path.join(PKG, "csrc", "wbc_qp.hip")])
     return out
 
 

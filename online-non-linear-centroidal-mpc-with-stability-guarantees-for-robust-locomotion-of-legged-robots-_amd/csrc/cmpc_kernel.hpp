@@ -667,10 +667,24 @@ template <int NV> struct Solver {
     const int vtx_i = is_force ? i / 3 : 0, a_i = i % 3, f_i = vtx_i / NV;
     // Lyapunov role: 0 c, 1 v, 2 theta, 3 V (force), -1 none.  Single-value selects on purpose: hipcc has
     // miscompiled if / else-if chains that assign several variables per branch (compiler note).
+#ifdef CMPC_REPRO_IFELSE
+    // Round-1 form (several assignments per branch), kept compilable as the reduced repro of the round-1 suspicion
+    // "hipcc miscompiles this chain in the 8-vertex kernel": built with -DCMPC_REPRO_IFELSE and run through the GPU
+    // parity tests in round 3 (tools/repro_ifelse.sh, profiles/r03_repro_ifelse.txt): see DESIGN.md section 5.
+    int ti = -1, ai = 0; double sci = 0.0;
+    if (stage) {
+      if (is_force) { ti = 3; ai = a_i; sci = gam[f_i] / m; }
+      else if (is_state && k >= 1) {
+        if (s < 3) { ti = 0; ai = s; sci = 1.0; } else if (s < 6) { ti = 1; ai = s - 3; sci = 1.0; }
+        else if (s >= 9 && s < 12) { ti = 2; ai = s - 9; sci = 1.0; }
+      }
+    }
+#else
     const int ts = (s < 3) ? 0 : (s < 6) ? 1 : ((s >= 9 && s < 12) ? 2 : -1);
     const int ti = !stage ? -1 : (is_force ? 3 : ((is_state && k >= 1) ? ts : -1));
     const int ai = is_force ? a_i : ((s < 3) ? s : (s < 6) ? s - 3 : s - 9);
     const double sci = is_force ? gam[f_i] / m : 1.0;
+#endif
     const int tic = (ti >= 0) ? ti : 0;
     const double al_i = al[i];
     const double sA = (ti >= 0) ? sigL * al_i : 0.0;
@@ -696,29 +710,40 @@ template <int NV> struct Solver {
 #pragma unroll
     for (int f = 0; f < 2; ++f) gm[f] = (ctype == 1 || (ctype >= 2 && f == cfoot)) ? gam[f] : 0.0;
     // force rows: mean-force coupling (same foot, same axis) and the friction block of the row's vertex
-    double mean_c = 0.0, fr0 = 0.0, fr1 = 0.0, diag = reg;
-    const double *sr5 = sig + R_FRIC + 5 * vtx_i;
-    if (stage && is_force) {
-      const double g1 = gam[f_i];
-      const double a_ = g1 * g1 / NV, coef = NV * a_ * a_ - 2 * a_;
-      const double wa = sp.w_force * g1, wb = sp.w_force * (1 - g1);
-      mean_c = 2 * wa * coef;
-      diag += 2 * wa + 2 * wb + mean_c;
-      if (a_i == 2 && k >= 1) diag += 2 * sp.w_rate * gam_km1(f_i);
-      const double g2 = g1 * g1;
-      if (a_i == 0) diag += g2 * (sr5[0] + sr5[1]);
-      else if (a_i == 1) diag += g2 * (sr5[2] + sr5[3]);
-      else {
-        diag += g2 * (muf * muf * (sr5[0] + sr5[1] + sr5[2] + sr5[3]) + sr5[4]);
-        fr0 = -g2 * muf * (sr5[0] - sr5[1]);
-        fr1 = -g2 * muf * (sr5[2] - sr5[3]);
-      }
-    }
+    // Every LDS word any row type needs is read here, unconditionally and at clamped indices, and the row type only
+    // picks its combination: written as nested if / else-if over the row type this block and the diagonal at the end
+    // were one exposed LDS round trip per branch (8 % of the kernel for a handful of flops; phase timers, round 3).
+    const double *sr5 = sig + R_FRIC + 5 * vtx_i;                     // (vtx_i = 0 for rows that are not forces)
+    const double s50 = sr5[0], s51 = sr5[1], s52 = sr5[2], s53 = sr5[3], s54 = sr5[4];
+    const double gkm0 = gam_km1(0), gkm1 = gam_km1(1);
+    const bool frow = stage && is_force;
+    const double g1 = f_i ? gam[1] : gam[0];
+    const double a_ = g1 * g1 / NV, coef = NV * a_ * a_ - 2 * a_;
+    const double wa = sp.w_force * g1, wb = sp.w_force * (1 - g1);
+    const double g2 = g1 * g1;
+    const double mean_c = frow ? 2 * wa * coef : 0.0;
+    const double d_rate = (a_i == 2 && k >= 1) ? 2 * sp.w_rate * (f_i ? gkm1 : gkm0) : 0.0;
+    const double d_fric = (a_i == 0) ? g2 * (s50 + s51) : (a_i == 1) ? g2 * (s52 + s53)
+                        : g2 * (muf * muf * (s50 + s51 + s52 + s53) + s54);
+    double diag = reg;                          // (terms added one by one, in the order of the branchy form: adding 0.0
+    diag += frow ? 2 * wa + 2 * wb + mean_c : 0.0;   //  keeps the bits, and with them the round-2 fixtures of the
+    diag += frow ? d_rate : 0.0;                //  ill-conditioned end game)
+    diag += frow ? d_fric : 0.0;
+    const double fr0 = (frow && a_i == 2) ? -g2 * muf * (s50 - s51) : 0.0;
+    const double fr1 = (frow && a_i == 2) ? -g2 * muf * (s52 - s53) : 0.0;
     const int j_fr0 = (stage && is_force && a_i == 2) ? 3 * vtx_i : -1;            // columns of fr0 / fr1
     // carried-force rows: rate coupling with the f_z column of the same vertex
     const bool is_fp = is_state && s >= CMPC_NX;
-    const double wr_fp = (is_fp && k >= 1 && stage) ? sp.w_rate * gam_km1((s - CMPC_NX) / NV) : 0.0;
+    const int f_fp = is_fp ? (s - CMPC_NX) / NV : 0;
+    const double wr_fp = (is_fp && k >= 1 && stage) ? sp.w_rate * (f_fp ? gkm1 : gkm0) : 0.0;
     const int j_fp = (is_fp && k >= 1 && stage) ? 3 * (s - CMPC_NX) + 2 : -1;
+    // words of the diagonal (state rows)
+    const int sc = is_state ? s : 0;
+    const bool s_c = is_state && s < 3, s_hw = is_state && s >= 6 && s < 9, s_yaw = is_state && (s == 12 || s == 16);
+    const bool s_pos = is_state && ((s >= 13 && s < 16) || (s >= 17 && s < 20));
+    const int f_ft = (s >= 16) ? 1 : 0, bidx = R_BOX + 6 * f_ft + 2 * (s_pos ? (s - 13) % 4 : 0);
+    const double sCZ = sig[R_CZ], zHW = L(D::oZK + R_HWC), sHW = sig[R_HWC], xs = x[sc];
+    const double gk0 = gam_k(k, 0), gk1 = gam_k(k, 1), sb0 = sig[bidx], sb1 = sig[bidx + 1];
     // constant part per (foot, axis) of a force column
     double cst[2][3];
 #pragma unroll
@@ -726,6 +751,7 @@ template <int NV> struct Solver {
 #pragma unroll
       for (int a = 0; a < 3; ++a)
         cst[f][a] = ((a == ai) ? hV * gam[f] : 0.0) + ((is_force && f == f_i && a == a_i) ? mean_c : 0.0) + gm[f] * cc0[a];
+    CMPC_TICK(9);
     // ---- force columns, one foot at a time (the batch of both feet held 8 NV doubles more than the register file
     // has to spare at this point: the only spills of the kernel came from here) ----
 #pragma unroll
@@ -749,6 +775,7 @@ template <int NV> struct Solver {
         }
       }
     }
+    CMPC_TICK(15);
     // ---- foot velocity columns: proximal term only ----
 #pragma unroll
     for (int j = 6 * NV; j < NU; ++j) *((j < wlim) ? row + j : dump) = 0.0;
@@ -769,25 +796,22 @@ template <int NV> struct Solver {
     }
 #pragma unroll 4
     for (int j = NU + 12; j < NZ; ++j) *((j < wlim) ? row + j : dump) = 0.0;
+    CMPC_TICK(23);
     // ---- diagonal ----
     // Lyapunov part: the (i, i) entry of the rank-1 term and of the multiplier-weighted constant Hessian
-    if (ti >= 0) diag += sA * al_i + (is_force ? hV * gam[f_i] : ((ti == 0) ? zq[0] : (ti == 1) ? zq[1] : zq[2]));
-    if (!is_state) {
-      if (stage) { if (!is_force) diag += 0.0; diag += sp.prox; } else diag = reg + 1.0;   // no inputs at the terminal node
-    } else {
-      if (k >= 1) {
-        if (s < 3) { diag += 2 * ((s == 2) ? wz : sp.w_cxy); if (s == 2) diag += sig[R_CZ]; }
-        else if (s >= 6 && s < 9) {
-          if (stage) diag += 2 * sp.w_hw;
-          if (k == 1) diag += 2 * L(D::oZK + R_HWC) + 4 * sig[R_HWC] * x[s] * x[s];
-        } else if (s == 12 || s == 16) { const double g = gam_k(k, s == 16); diag += 2 * sp.w_foot * g * g; }
-        else if ((s >= 13 && s < 16) || (s >= 17 && s < 20)) {
-          const int f = (s >= 17), a = (s - 13) % 4; const double g = gam_k(k, f);
-          diag += 2 * sp.w_foot * g * g + g * g * (sig[R_BOX + 6 * f + 2 * a] + sig[R_BOX + 6 * f + 2 * a + 1]);
-        } else if (is_fp && stage) diag += 2 * wr_fp;
-      }
-      if (ctype == 3) diag += L(D::oMISC + 30 + cfoot);
-    }
+    const double q30 = L(D::oMISC + 30 + cfoot);
+    if (ti >= 0) diag += sA * al_i + (is_force ? hV * g1 : ((ti == 0) ? zq[0] : (ti == 1) ? zq[1] : zq[2]));
+    const bool kp = k >= 1;
+    const double gk = f_ft ? gk1 : gk0;
+    diag += (kp && s_c) ? 2 * ((s == 2) ? wz : sp.w_cxy) : 0.0;
+    diag += (kp && s_c && s == 2) ? sCZ : 0.0;
+    diag += (kp && s_hw && stage) ? 2 * sp.w_hw : 0.0;
+    diag += (kp && s_hw && k == 1) ? 2 * zHW + 4 * sHW * xs * xs : 0.0;
+    diag += (kp && s_yaw) ? 2 * sp.w_foot * gk * gk : 0.0;
+    diag += (kp && s_pos) ? 2 * sp.w_foot * gk * gk + gk * gk * (sb0 + sb1) : 0.0;
+    diag += (kp && is_fp && stage) ? 2 * wr_fp : 0.0;
+    diag += (ctype == 3) ? q30 : 0.0;
+    diag = is_state ? diag : (stage ? diag + sp.prox : reg + 1.0);   // no inputs at the terminal node
     if (live) row[i] = diag;
   }
 
@@ -1069,7 +1093,6 @@ template <int NV> struct Solver {
     if constexpr (NU > 32) { if (!chol_block<32>(M, ok, (NU > 48) || k > 0)) return false; }
     if constexpr (NU > 48) { if (!chol_block<48>(M, ok, k > 0)) return false; }
     CMPC_TICK(8);
-    CMPC_TICK(9);
     return true;
   }
 
@@ -1294,10 +1317,10 @@ template <int NV> struct Solver {
         CMPC_TICK(13);
         CMPC_RELANE(lane); CMPC_OPAQUE(lane);
         add_GtPG();
-        CMPC_TICK(15);
+        CMPC_TICK(14);
         CMPC_RELANE(lane); CMPC_OPAQUE(lane);
         if (!factor_stage(k)) return false;
-        CMPC_TICK(23);
+        CMPC_TICK(8);
         backward_vectors(k);
         CMPC_TICK(5);
       } else {

@@ -49,9 +49,10 @@ def test_state_batch_matches_single_instances_and_plain_entry_point(oracle):
     assert torch.equal(a, b) and torch.equal(it_a, it_b)
     # every instance again from its own state and solution: a handful of iterations, the same optimum
     c, st_c, it_c, _ = solver.solve(d, warm=b, state=s2, state_out=s1)
-    ok = (st_b == 0) & (st_c == 0)
-    assert ok.float().mean() > 0.9 and it_c[ok].float().mean() < 0.5 * it_b[ok].float().mean()
-    assert np.median(rel_inf(c[ok].cpu().numpy(), b[ok].cpu().numpy())) < 1e-6
+    w, st_w, it_w, _ = solver.solve(d, warm=b)                              # the same problem (proximal centre b) the plain way
+    ok = (st_w == 0) & (st_c == 0)
+    assert ok.float().mean() > 0.9 and it_c[ok].float().mean() < 0.6 * it_w[ok].float().mean()
+    assert np.median(rel_inf(c[ok].cpu().numpy(), w[ok].cpu().numpy())) < 1e-6
     # and the batch is the sum of its instances (bitwise)
     for i in (0, 17, 95):
         ci, _, it_i, _ = solver.solve(d[i:i + 1], warm=b[i:i + 1], state=s2[i:i + 1].clone(), state_out=solver.new_state(1))

@@ -25,8 +25,8 @@ assert lib.cmpc_profile_read(s._h, buf) == 0
 n_it = float(iters.sum().item())
 v = np.array(list(buf), dtype=np.float64)
 names = {24: "stage iterates: load + LDS commit", 11: "geometry", 12: "inequality rows", 25: "barrier weights", 26: "gradient / residual",
-         0: "slab stores of the evaluation", 1: "Hessian rows", 13: "P b", 10: "G'PG: T = P[B A]", 14: "G'PG: M += [B A]'T", 15: "(G'PG tail)",
-         19: "Cholesky: trailing write-back of the previous block + block load", 20: "Cholesky: pivot chain + in-block updates", 21: "Cholesky: block store", 22: "MFMA trailing update", 23: "trailing write-back", 8: "(factor tail)", 9: "(factor tail)",
+         0: "slab stores of the evaluation", 1: "Hessian rows: diagonal", 9: "Hessian rows: row roles and coefficients", 15: "Hessian rows: force columns", 23: "Hessian rows: velocity and state columns", 13: "P b", 10: "G'PG: T = P[B A]", 14: "G'PG: M += [B A]'T", 
+         19: "Cholesky: trailing write-back of the previous block + block load", 20: "Cholesky: pivot chain + in-block updates", 21: "Cholesky: block store", 22: "MFMA trailing update",  8: "(factor tail)",
          2: "backward vectors: m", 3: "backward vectors: l", 5: "backward vectors: p", 4: "factor store",
          16: "forward sweep: loads", 17: "forward sweep: du, slack directions", 18: "forward sweep: dx", 6: "(forward tail + reductions)", 7: "step application"}
 tot = v.sum()
