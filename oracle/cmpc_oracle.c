@@ -36,7 +36,9 @@
 
 /* termination safeguards (mirrored by the HIP solver) */
 #define ACC_FACTOR 100.0
+#ifndef ACC_ITERS
 #define ACC_ITERS 8
+#endif
 /* no progress at the final barrier value: NOPROG_ITERS iterations without halving the best KKT error
  * seen there.  The run then ends as CMPC_ACCEPTABLE as soon as the error is within spec.acc_tol. */
 #define NOPROG_ITERS 12

@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage (GPU box, repo root): bash tools/round_report.sh r03b   -- everything profiles/ holds for a round, in one call
+tag=${1:-rXX}
+out=$PWD/gpurun_out/$tag
+mkdir -p "$out"
+python -m pytest tests -m gpu -q > "$out/gpu_tests.log" 2>&1; echo "gpu tests rc $?"; tail -2 "$out/gpu_tests.log"
+bash tools/profile_round.sh $tag > "$out/profile_round.log" 2>&1; tail -3 "$out/profile_round.log"
+bash tools/pmc_stall.sh "$out/pmc_stall" > "$out/pmc_stall.log" 2>&1; echo "pmc done"
+python bench.py --workload perturbed --batch 256 --steps 6 --warmup 1 --no-extras --no-cpu-baseline > "$out/bench_line_perturbed.json" 2>/dev/null
+python bench.py --workload payload --batch 4096 --steps 6 --warmup 1 --no-extras --no-cpu-baseline > "$out/bench_line_payload.json" 2>/dev/null
+python bench.py --workload long_horizon --steps 4 --warmup 1 --no-extras --no-cpu-baseline > "$out/bench_line_long_horizon.json" 2>/dev/null
+echo "config lines done"
+python tools/walk_demo.py > "$out/walk_demo.txt" 2>&1; tail -2 "$out/walk_demo.txt"
+python tools/parity_report.py > "$out/parity_report.txt" 2>&1; echo "parity report done"
+for w in "randomized 8192" "payload 4096" "perturbed 4096"; do python tools/full_parity.py $w; done > "$out/full_parity.txt" 2>&1; tail -4 "$out/full_parity.txt"
+CMPC_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 2 --warmup 1 --no-extras --no-cpu-baseline > "$out/selflaunch_2rank.json" 2> "$out/selflaunch_2rank.err"; echo "self-launch rc $?"
