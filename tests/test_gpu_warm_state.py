@@ -57,3 +57,56 @@ def test_state_batch_matches_single_instances_and_plain_entry_point(oracle):
     for i in (0, 17, 95):
         ci, _, it_i, _ = solver.solve(d[i:i + 1], warm=b[i:i + 1], state=s2[i:i + 1].clone(), state_out=solver.new_state(1))
         assert torch.equal(ci[0], c[i]) and int(it_i[0]) == int(it_c[i])
+
+
+def test_state_edge_cases_stale_state_nan_record_and_horizon_limits(oracle):
+    """(a) a state written for a tick far away (another contact phase, pushed CoM) must not do harm: the solve ends with
+    the plain solve's optimum, by its own iterations or through the fallback; (b) a NaN record (out-of-range tick of
+    the device builder) ends with status 2 and leaves an invalid state behind; (c) the smallest and the largest horizon
+    of the build (N = 1, N = CMPC_MAX_N = 64) take the state path too."""
+    sc = wl.scene()
+    spec = ProblemSpec(N=10)
+    solver = BatchedCentroidalMPC(spec, device="cuda:0")
+    HW = np.loadtxt(__file__.rsplit("/", 1)[0] + "/golden/measured_hw_cuhw.txt")
+
+    def rec_at(t, dcom_push=0.0):
+        com, dcom = sc.nominal_state(np.array([t]))
+        return sc.build_records(spec, np.array([t]), com, dcom + dcom_push, HW[t][None], np.zeros((1, 3)), np.zeros(1),
+                                np.zeros(1), np.full(1, wl.HRP4_MASS), np.full(1, 0.5))
+
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    s0, s1, s2 = solver.new_state(1), solver.new_state(1), solver.new_state(1)
+    a, st_a, it_a, _ = solver.solve(dev(rec_at(120)), state=s0, state_out=s1)            # double support, t = 120
+    assert int(st_a[0]) == 0 and float(s1[0, -8 - 2 * 11]) > 0
+    far = dev(rec_at(640, dcom_push=0.08))                                               # single support, five steps later, pushed
+    b, st_b, it_b, _ = solver.solve(far, warm=a, state=s1, state_out=s2)
+    c, st_c, it_c, _ = solver.solve(far, warm=a)
+    assert int(st_b[0]) in (0, 3) and int(st_c[0]) in (0, 3)
+    cs = oracle_spec(oracle, spec)
+    up = a[0].cpu().numpy()[20 * 11:]
+    f_b = oracle.evaluate(cs, rec_at(640, 0.08)[0], b[0].cpu().numpy(), uprox=up)[0]
+    f_c = oracle.evaluate(cs, rec_at(640, 0.08)[0], c[0].cpu().numpy(), uprox=up)[0]
+    assert abs(f_b - f_c) <= 1e-7 * abs(f_c) and rel_inf(b.cpu().numpy(), c.cpu().numpy())[0] < 1e-3
+    assert int(it_b[0]) <= int(it_c[0]) + 60                                             # (fallback: both attempts are counted)
+    # (b)
+    bad = rec_at(300); bad[0, 30] = np.nan
+    s3 = solver.new_state(1)
+    _, st_n, _, _ = solver.solve(dev(bad), warm=a, state=s1, state_out=s3)
+    assert int(st_n[0]) == 2 and float(s3[0, -8 - 2 * 11]) == 0.0
+    # (c)
+    for N in (1, 64):
+        sp = ProblemSpec(N=N)
+        so = BatchedCentroidalMPC(sp, device="cuda:0")
+        com, dcom = sc.nominal_state(np.array([230]))
+        r = sc.build_records(sp, np.array([230]), com, dcom, HW[230][None], np.zeros((1, 3)), np.zeros(1), np.zeros(1),
+                             np.full(1, wl.HRP4_MASS), np.full(1, 0.5))
+        t0, t1 = so.new_state(1), so.new_state(1)
+        x, st_x, it_x, _ = so.solve(dev(r), state=t0, state_out=t1)
+        y, st_y, it_y, _ = so.solve(dev(r), warm=x, state=t1, state_out=t0)
+        ref, st_r, _, _ = oracle.solve_batch(oracle_spec(oracle, sp), r)
+        assert int(st_x[0]) in (0, 3) and int(st_y[0]) in (0, 3) and st_r[0] in (0, 3)
+        assert rel_inf(x.cpu().numpy(), ref)[0] < 1e-4
+        # N = 1 resumes in a handful of iterations; at N = 64 the end game needs inertia corrections of 1 ... 50 and
+        # hovers at ~1e-8 for as long as it is allowed to, resumed or not (oracle: cold 43 iterations "acceptable", the
+        # same tolerance-level point): only the outcome is asserted there
+        assert N == 64 or int(it_y[0]) < int(it_x[0])
