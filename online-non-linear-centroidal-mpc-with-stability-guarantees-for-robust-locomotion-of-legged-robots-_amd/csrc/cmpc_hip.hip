@@ -43,10 +43,12 @@ __global__ void __launch_bounds__(256) cmpc_order_kernel(int B, int N, const dou
   else order[B - 1 - atomicAdd(counters + 2, 1)] = i;
 }
 
-template <int NV>
-__global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_solve_kernel(cmpc::KArgs ka, int *ticket,
-                                                                                              const int *__restrict__ order) {
-  using D = cmpc::Dims<NV>;
+// One workgroup per instance in flight: a single wave for the 4-vertex solver, NW = WAVES_NV8 waves for the 8-vertex
+// one (its stage block has 92 rows: with 128 lanes every row / column has its own lane, cmpc_kernel.hpp).
+template <int NV, int NW>
+__global__ void __launch_bounds__(64 * NW, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_solve_kernel(cmpc::KArgs ka, int *ticket,
+                                                                                                   const int *__restrict__ order) {
+  using D = cmpc::Dims<NV, NW>;
   __shared__ __attribute__((aligned(16))) double lds[D::LDS_DOUBLES];
   __shared__ int next;
   double *slab = ka.scratch + (size_t)blockIdx.x * ka.scratch_stride;
@@ -60,7 +62,7 @@ __global__ void __launch_bounds__(64, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) cmpc_
     // the queue position comes out of LDS in a vector register; the instance index is wave-uniform, and saying so
     // keeps the record / output base addresses in scalar registers
     const int p = __builtin_amdgcn_readfirstlane(order[__builtin_amdgcn_readfirstlane(tk)]);
-    cmpc::Solver<NV> s(ka, lds, slab, ka.recs + (size_t)p * nrec);
+    cmpc::Solver<NV, NW> s(ka, lds, slab, ka.recs + (size_t)p * nrec);
     s.solve(ka.warm ? ka.warm + (size_t)p * nsol : nullptr, ka.state_in ? ka.state_in + (size_t)p * nstate : nullptr,
             ka.state_out ? ka.state_out + (size_t)p * nstate : nullptr, ka.out + (size_t)p * nsol, ka.status + p,
             ka.iters + p, ka.kkt + p);
@@ -182,10 +184,10 @@ static bool spec_ok(const cmpc_spec *s) {
          s->acc_tol > 0 && s->acc_tol < INFINITY;
 }
 static size_t lds_bytes(int nv) {
-  return sizeof(double) * (nv == 4 ? cmpc::Dims<4>::LDS_DOUBLES : cmpc::Dims<8>::LDS_DOUBLES) + 16;
+  return sizeof(double) * (nv == 4 ? cmpc::Dims<4>::LDS_DOUBLES : cmpc::Dims<8, cmpc::WAVES_NV8>::LDS_DOUBLES) + 16;
 }
 static size_t slab_doubles(const cmpc_spec *s) {
-  return s->nv == 4 ? cmpc::Dims<4>::scratch_doubles(s->N) : cmpc::Dims<8>::scratch_doubles(s->N);
+  return s->nv == 4 ? cmpc::Dims<4>::scratch_doubles(s->N) : cmpc::Dims<8, cmpc::WAVES_NV8>::scratch_doubles(s->N);
 }
 static int resident_per_cu(int nv) {
   int n = (int)((160 * 1024) / lds_bytes(nv));
@@ -292,9 +294,9 @@ int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, cons
   HIP_TRY(h, hipEventRecord(h->ev0, st));
   hipLaunchKernelGGL(cmpc_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->spec.N, params, h->order, h->ticket);
   if (h->spec.nv == 4)
-    hipLaunchKernelGGL(cmpc_solve_kernel<4>, dim3(grid), dim3(64), 0, st, ka, h->ticket, h->order);
+    hipLaunchKernelGGL((cmpc_solve_kernel<4, 1>), dim3(grid), dim3(64), 0, st, ka, h->ticket, h->order);
   else
-    hipLaunchKernelGGL(cmpc_solve_kernel<8>, dim3(grid), dim3(64), 0, st, ka, h->ticket, h->order);
+    hipLaunchKernelGGL((cmpc_solve_kernel<8, cmpc::WAVES_NV8>), dim3(grid), dim3(64 * cmpc::WAVES_NV8), 0, st, ka, h->ticket, h->order);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev1, st));
   h->timed = true;

@@ -36,6 +36,10 @@
 // CMPC_SYNC_GLOBAL() is the full fence, used where lanes exchange data through the global slab.
 #define CMPC_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define CMPC_SYNC_GLOBAL() __syncthreads()
+// Two waves per instance (Solver<NV, 2>): every LDS hand-off is a workgroup barrier.  The source carries a CMPC_SYNC at
+// every cross-lane hand-off (the host emulation runs the lanes as threads), so the same code is correct for 128 lanes.
+#define CMPC_SYNC_WG() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define CMPC_WAVE_ID() ((int)__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6))
 // value held by lane `src` (wave-uniform index) broadcast to every lane, no LDS round trip
 static __device__ __forceinline__ double cmpc_bcast(double v, int src) {
   union { double d; int i[2]; } u; u.d = v;
@@ -57,7 +61,7 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 #define CMPC_OPAQUE_D(x) asm volatile("" : "+v"(x))
 // the lane id again from the execution mask (two instructions): where it is re-derived the old value need not stay
 // live -- or be spilled -- across the code in front (one wave per workgroup: lane id = thread id)
-#define CMPC_RELANE(x) do { (x) = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); } while (0)
+#define CMPC_RELANE(x) do { (x) = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) + 64 * wv; } while (0)
 #endif
 #ifndef CMPC_RELANE
 #define CMPC_RELANE(x) do { } while (0)
@@ -115,6 +119,8 @@ constexpr double MU_FACTOR = 0.1;
 // warm start of the interior point method: the solver state is the iterate at the last barrier value >= MU_WARM
 // (see the oracle for the choice of the level)
 constexpr double MU_WARM = 1e-7;
+// waves per instance of the 8-vertex solver (Solver<8, WAVES_NV8>; the 4-vertex one is a single wave)
+constexpr int WAVES_NV8 = 2;
 
 #ifndef CMPC_NO_DEVICE_CODE
 #include "cmpc_lds_asm.hpp"
@@ -144,14 +150,16 @@ template <int CNT> CMPC_DEV void lds_read_row(double (&v)[CNT], const double *p)
 }
 #endif
 
-template <int NV> struct Dims {
+template <int NV, int NW = 1> struct Dims {
+  static_assert(NW == 1 || NW == 2, "one or two waves per instance");
+  static constexpr int WS = 64 * NW;          // lanes of the workgroup that owns an instance
   static constexpr int NF = 2 * NV;           // contact vertices
   static constexpr int NU = 6 * NV + 8;
   static constexpr int NXA = CMPC_NX + 2 * NV;
   static constexpr int NZ = NU + NXA;
   static constexpr int NI = 15 + 10 * NV;
   static constexpr int NTRI = NZ * (NZ + 1) / 2;
-  static constexpr int NH = (NZ + 63) / 64;   // rows / columns of the stage block owned by one lane
+  static constexpr int NH = (NZ + WS - 1) / WS;   // rows / columns of the stage block owned by one lane
   static constexpr int PS = NXA + 1;          // odd row strides: conflict-free column access
   static constexpr int LS = NU + 1;
   static constexpr int TH = (NZ + 1) / 2;     // columns per half of T = P [B A]
@@ -195,20 +203,20 @@ template <int NV> struct Dims {
   // [oSK, oTV + NZ) when it fits (nv = 4): all of them are dead between build_H and the next
   // stage's load.  Otherwise (nv = 8) it gets its own region.
   static constexpr bool T_ALIAS = (oSK + NXA * TS <= oTV + NZ);
-  static constexpr int oT = T_ALIAS ? oSK : oDUMP + 64;
+  static constexpr int oT = T_ALIAS ? oSK : oDUMP + WS;
   // (+ T_PAD: add_GtPG reads the T rows in batches of 10 columns whatever the row's length; the tail of the
   // last row must still be inside the allocation)
   static constexpr int T_PAD = 10;
-  static constexpr int LDS_DOUBLES = T_ALIAS ? oDUMP + 64 : oDUMP + 64 + NXA * TS + T_PAD;
+  static constexpr int LDS_DOUBLES = T_ALIAS ? oDUMP + WS : oDUMP + WS + NXA * TS + T_PAD;
   // ---- global scratch map per stage (doubles) ----
   // The factorised stage block as it stands in LDS, a packed lower triangle of NZ rows, copied word for word:
   // rows 0..NU-1 hold Lambda, row NU+c holds [Ls row c | P_k row c up to the diagonal].  (Round 2 wrote Lambda as a
   // zero-filled NU x NU square and Ls | P_k as NXA full 64-word rows: 2816 words per stage against 1830.)
   static constexpr int gM = 0;
-  static constexpr bool W_MERGE = (NZ <= 64);            // forward sweep: lanes >= NU take the P_k columns
+  static constexpr bool W_MERGE = (NZ <= WS);            // forward sweep: lanes >= NU take the P_k columns
   static constexpr int gAL = ((NTRI + 7) / 8) * 8;
   static constexpr int gGH = gAL + NZ;
-  static constexpr int GHS = 64 * NH;      // row stride of the three dense dynamics rows in the slab
+  static constexpr int GHS = WS * NH;      // row stride of the three dense dynamics rows in the slab
   static constexpr int gB = gGH + 3 * GHS;
   static constexpr int gPB = gB + NXA;
   static constexpr int gPV = gPB + NXA;
@@ -250,16 +258,18 @@ struct GArr {
   CMPC_DEV cmpc_v2d &pair(unsigned i) const { return *(cmpc_v2d *)((char *)p + (size_t)(i * 16u)); }   // 16-byte aligned pairs
 };
 
-template <int NV> struct Solver {
-  using D = Dims<NV>;
-  static constexpr int NF = D::NF, NU = D::NU, NXA = D::NXA, NZ = D::NZ, NI = D::NI, NH = D::NH;
+template <int NV, int NW = 1> struct Solver {
+  using D = Dims<NV, NW>;
+  static constexpr int NF = D::NF, NU = D::NU, NXA = D::NXA, NZ = D::NZ, NI = D::NI, NH = D::NH, WS = D::WS;
+  static_assert(NW == 1 || NU <= 64, "the input rows (pivot chains, substitutions) live in the first wave");
 
   const KArgs &ka;
   const cmpc_spec &sp;
   double *lds;
   GArr gs;                 // this workgroup's scratch slab
   GArr rec;                // this instance's parameter record (read only)
-  int N, lane;
+  int N, lane;               // lane: 0 .. WS-1 over the workgroup (two waves: 64 * wave + lane of the wave)
+  int wv = 0;                // wave of the workgroup (0 when NW = 1), wave-uniform
   // global iterate arrays
   GArr gx, glam, gdx, glamn, gu, gdu, gupx, gsl, gz, gds, gdz;
   // per-lane column list of [B A]: rows / coefficients (id, h0, h1, h2, sp1, sp2)
@@ -271,6 +281,7 @@ template <int NV> struct Solver {
 
   CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
       : ka(a), sp(a.sp), lds(l), gs{g}, rec{const_cast<double *>(r)}, N(a.sp.N), lane(CMPC_LANE) {
+    if constexpr (NW > 1) wv = CMPC_WAVE_ID();
     double *p = g + (size_t)(N + 1) * D::STAGE;
     gx = GArr{p}; p += (size_t)(N + 1) * NXA;
     glam = GArr{p}; p += (size_t)(N + 1) * NXA;
@@ -286,6 +297,15 @@ template <int NV> struct Solver {
   }
   CMPC_DEV GArr stage(int k) const { return GArr{gs.p + (size_t)k * D::STAGE}; }
   CMPC_DEV double &L(int o) const { return lds[o]; }
+  // LDS hand-off between lanes: one wave needs only its own LDS traffic drained, two waves a workgroup barrier
+  CMPC_DEV void sync() const {
+#ifdef CMPC_HOST_EMU
+    CMPC_SYNC();
+#else
+    if constexpr (NW == 1) CMPC_SYNC(); else CMPC_SYNC_WG();
+#endif
+  }
+  CMPC_DEV bool first_wave() const { return NW == 1 || wv == 0; }
 
   // contact flag gamma_f at node k and k-1 from the staged records
   CMPC_DEV double gam_k(int k, int f) const { return (k == N) ? L(D::oHDR + 22 + f) : L(D::oSR + 17 + f); }
@@ -305,7 +325,7 @@ template <int NV> struct Solver {
   // one exposed HBM round trip each (load, s_waitcnt vmcnt(0), ds_write), a dozen per stage.
   CMPC_DEV void load_stage(int k) {
     static_assert(NXA <= 64 && NU <= 64, "one lane per state / input component");
-    constexpr int NIH = (NI + 63) / 64;
+    constexpr int NIH = (NI + WS - 1) / WS;
     const bool in = k < N;
     const int kn = in ? k + 1 : k, ku = in ? k : N - 1, kp = (k >= 1) ? k - 1 : 0;
     const int ix = (lane < NXA) ? lane : 0, iu = (lane < NU) ? lane : 0, ir = (lane < 19) ? lane : 0;
@@ -317,7 +337,7 @@ template <int NV> struct Solver {
     {
 #pragma unroll
       for (int h = 0; h < NIH; ++h) {
-        const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
+        const int r = lane + WS * h, rc = (r < NI) ? r : 0;
         sv[h] = gsl[k * NI + rc]; zv[h] = gz[k * NI + rc];
       }
     }
@@ -329,13 +349,13 @@ template <int NV> struct Solver {
     {
 #pragma unroll
       for (int h = 0; h < NIH; ++h) {
-        const int r = lane + 64 * h;
+        const int r = lane + WS * h;
         if (r < NI) { L(D::oSK + r) = sv[h]; L(D::oZK + r) = zv[h]; }
       }
     }
     if (lane < 19) { L(D::oSR + lane) = in ? r0 : 0.0; L(D::oSRP + lane) = (k >= 1) ? r1 : 0.0; }
     if (lane < 24) L(D::oHDR + lane) = hd;
-    CMPC_SYNC();
+    sync();
   }
 
   // ---------------------------------------------------------------------------------------
@@ -372,7 +392,7 @@ template <int NV> struct Solver {
       qq[lane] = p0 * (-rvy * fz) + p1 * (rvx * fz) + p2 * (-rvx * fy + rvy * fx);   // pi . ((R''v) x f), R''v = -Rv
       if (lane < 3) L(D::oMISC + 9 + lane) = (lane == 0) ? p0 : (lane == 1) ? p1 : p2;
     }
-    CMPC_SYNC();
+    sync();
     // (B) sums over the vertices, one lane per result, every lane the same NF independent reads:
     //   lanes 0..5   Fs[f][a]  = sum_j f_j[a]                         -> MISC 0..5
     //   lanes 6..8   tau[a]    = sum_f gamma_f sum_j (r_j x f_j)[a]    -> MISC 6..8
@@ -397,9 +417,9 @@ template <int NV> struct Solver {
       }
       L(D::oMISC + dst) = acc;
     }
-    CMPC_SYNC();
+    sync();
     // GH[a][col]: rows 6..8 of [B A] minus identity
-    for (int col = lane; col < NZ; col += 64) {
+    for (int col = lane; col < NZ; col += WS) {
       double g0 = 0, g1 = 0, g2 = 0;
       if (col < 6 * NV) {                    // force component: d*gamma*skew(r)[.][a]
         const int v = col / 3, a = col % 3, f = v / NV;
@@ -448,7 +468,7 @@ template <int NV> struct Solver {
       else xn = u[3 * (q - 20) + 2];
       L(D::oBV + q) = xn - L(D::oXN1 + q);
     }
-    CMPC_SYNC();
+    sync();
   }
 
   // Column list of [B A] for this lane's column (lane < NZ): id, 3 h-rows, 2 specials.
@@ -460,7 +480,7 @@ template <int NV> struct Solver {
       double *g = lg[h];
 #pragma unroll
       for (int n = 0; n < 6; ++n) { r[n] = 0; g[n] = 0.0; }
-      const int col = lane + 64 * h;
+      const int col = lane + WS * h;
       if (col >= NZ) continue;
       r[1] = 6; r[2] = 7; r[3] = 8;
       g[1] = gh[col]; g[2] = gh[NZ + col]; g[3] = gh[2 * NZ + col];
@@ -503,12 +523,12 @@ template <int NV> struct Solver {
       L(D::oMISC + 47 + a) = V;
       L(D::oRED + a) = -k1 * z1 * z1 - k2 * z2 * z2 + z1 * z2 + z2 * (V - un);
     }
-    CMPC_SYNC();
+    sync();
     // Lyapunov gradient over z = (u, x): every column is c1 * MISC[i1] + c2 * MISC[i2]; the same two
     // reads for every lane instead of one divergent path per column type
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      const int col = lane + 64 * h, cc = (col < NZ) ? col : 0;
+      const int col = lane + WS * h, cc = (col < NZ) ? col : 0;
       const bool is_f = cc < 6 * NV, is_x = cc >= NU;
       const int a = cc % 3, f = (cc / 3) / NV, sx = is_x ? cc - NU : 0;
       const int grp = (sx < 3) ? 0 : (sx < 6) ? 1 : ((sx >= 9 && sx < 12) ? 2 : 3);   // c, v, theta, none
@@ -522,7 +542,7 @@ template <int NV> struct Solver {
     }
     // Inequality rows: one batch of clamped reads per lane, the row type picks its combination
     {
-      constexpr int NIH = (NI + 63) / 64;
+      constexpr int NIH = (NI + WS - 1) / WS;
       const double x2 = L(D::oXK + 2), x6 = L(D::oXK + 6), x7 = L(D::oXK + 7), x8 = L(D::oXK + 8);
       const double h6 = L(D::oHDR + 6), h7 = L(D::oHDR + 7), h8 = L(D::oHDR + 8);   // hw_0 (record header = x_0)
       const double hw0n2 = h6 * h6 + h7 * h7 + h8 * h8;
@@ -530,7 +550,7 @@ template <int NV> struct Solver {
       const double red = L(D::oRED) + L(D::oRED + 1) + L(D::oRED + 2);
 #pragma unroll
       for (int h = 0; h < NIH; ++h) {
-        const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
+        const int r = lane + WS * h, rc = (r < NI) ? r : 0;
         const bool is_box = rc >= R_BOX && rc < R_FRIC, is_fr = rc >= R_FRIC;
         const int qb = is_box ? rc - R_BOX : 0, fb = qb / 6, ab = (qb % 6) / 2;
         const int qf = is_fr ? rc - R_FRIC : 0, v = qf / 5, t = qf % 5;
@@ -554,7 +574,7 @@ template <int NV> struct Solver {
         }
       }
     }
-    CMPC_SYNC();
+    sync();
   }
 
   // (Jg' w)[col] for row weights w (zero on inactive rows).
@@ -635,7 +655,7 @@ template <int NV> struct Solver {
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void build_H(int k, double reg, double wz) {
 #pragma unroll 1
-    for (int h_ = 0; h_ < NH; ++h_) build_H_row(k, reg, wz, lane + 64 * h_);
+    for (int h_ = 0; h_ < NH; ++h_) build_H_row(k, reg, wz, lane + WS * h_);
   }
   // One pass over the columns, the same instruction stream for every row: the column type (force
   // axis / foot, velocity, state group) is wave-uniform, everything that depends on the row is a
@@ -828,7 +848,7 @@ template <int NV> struct Solver {
       const int c0 = half * D::TH, c1 = (c0 + D::TH < NZ) ? c0 + D::TH : NZ;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {           // column of T = P [B A] owned by this lane in this half
-        const int col = lane + 64 * h;
+        const int col = lane + WS * h;
         if (col >= c0 && col < c1) {
 #pragma unroll 1
           for (int q0 = 0; q0 < NXA; q0 += QT) {
@@ -852,11 +872,11 @@ template <int NV> struct Solver {
           }
         }
       }
-      CMPC_SYNC();
+      sync();
       CMPC_TICK(10);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {           // owned row of M, columns c0 .. min(row, c1-1)
-        const int rowi = lane + 64 * h;
+        const int rowi = lane + WS * h;
         if (rowi >= c0 && rowi < NZ) {
           const int iend = ((rowi < c1 - 1) ? rowi : c1 - 1) - c0;   // last column, relative to c0
 #pragma unroll 1
@@ -884,7 +904,7 @@ template <int NV> struct Solver {
           }
         }
       }
-      CMPC_SYNC();
+      sync();
       CMPC_TICK(14);
     }
   }
@@ -927,7 +947,7 @@ template <int NV> struct Solver {
     double *dump = &L(D::oDUMP + lane);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      const int rowi = lane + 64 * h;
+      const int rowi = lane + WS * h;
       const bool own = rowi >= C0 && rowi < NZ;
       const double *ri = M + tri(own ? rowi : C0) + C0;
 #pragma unroll
@@ -938,7 +958,7 @@ template <int NV> struct Solver {
     for (int p = 0; p < W / 4; ++p) {
       const int J = C0 + 4 * p;
       double t10, t20, t21, t30, t31, t32, i0, i1, i2, i3;
-      {                                        // the panel itself (first row set): pivots and multipliers by readlane
+      if (first_wave()) {                      // the panel itself (first row set): pivots and multipliers by readlane
         double a0 = blk[0][4 * p], a1 = blk[0][4 * p + 1], a2 = blk[0][4 * p + 2], a3 = blk[0][4 * p + 3];
         const double p0 = CMPC_BCAST(a0, J);
         ok = ok && (p0 > piv_min);
@@ -964,6 +984,25 @@ template <int NV> struct Solver {
         const double l3 = (lane == J + 3) ? s3 : a3 * i3;
         blk[0][4 * p] = l0; blk[0][4 * p + 1] = l1; blk[0][4 * p + 2] = l2; blk[0][4 * p + 3] = l3;
       }
+      if constexpr (NW > 1) {
+        // the second wave's rows are "further rows": the first wave hands it the panel's reciprocals and
+        // multipliers (and the pivot verdict) through eleven LDS words behind the in-block table of the T tile
+        double *pk = &L(D::oT + 64);
+        if (lane == 0) {
+          pk[0] = ok ? 1.0 : 0.0; pk[1] = i0; pk[2] = i1; pk[3] = i2; pk[4] = i3;
+          pk[5] = t10; pk[6] = t20; pk[7] = t21; pk[8] = t30; pk[9] = t31; pk[10] = t32;
+        }
+        sync();
+        if (wv != 0) {
+          ok = pk[0] != 0.0; i0 = pk[1]; i1 = pk[2]; i2 = pk[3]; i3 = pk[4];
+          t10 = pk[5]; t20 = pk[6]; t21 = pk[7]; t30 = pk[8]; t31 = pk[9]; t32 = pk[10];
+          const double l0 = blk[0][4 * p] * i0;
+          const double l1 = (blk[0][4 * p + 1] - l0 * t10) * i1;
+          const double l2 = (blk[0][4 * p + 2] - (l0 * t20 + l1 * t21)) * i2;
+          const double l3 = (blk[0][4 * p + 3] - (l0 * t30 + l1 * t31 + l2 * t32)) * i3;
+          blk[0][4 * p] = l0; blk[0][4 * p + 1] = l1; blk[0][4 * p + 2] = l2; blk[0][4 * p + 3] = l3;
+        }
+      }
 #pragma unroll
       for (int h = 1; h < NH; ++h) {           // further row sets reuse the broadcast multipliers
         const double l0 = blk[h][4 * p] * i0;
@@ -972,7 +1011,7 @@ template <int NV> struct Solver {
         const double l3 = (blk[h][4 * p + 3] - (l0 * t30 + l1 * t31 + l2 * t32)) * i3;
         blk[h][4 * p] = l0; blk[h][4 * p + 1] = l1; blk[h][4 * p + 2] = l2; blk[h][4 * p + 3] = l3;
       }
-      if (!ok) return false;                   // pivots are wave-uniform
+      if (!ok) return false;                   // pivots are uniform over the instance's lanes
       // right-looking inside the block: the remaining block columns of every row.  The multipliers of
       // the block's later rows are handed over through a small LDS table (the T tile is dead here) and
       // read back at wave-uniform addresses: one ds_read per pair of doubles on the LDS port instead of
@@ -988,7 +1027,7 @@ template <int NV> struct Solver {
           *(src ? w + 2 : dump) = blk[0][4 * p + 2];
           *(src ? w + 3 : dump) = blk[0][4 * p + 3];
         }
-        CMPC_SYNC();
+        sync();
 #pragma unroll
         for (int cc = 4 * p + 4; cc < W; ++cc) {
           const double u0 = ub[4 * cc], u1 = ub[4 * cc + 1], u2 = ub[4 * cc + 2], u3 = ub[4 * cc + 3];
@@ -1005,18 +1044,20 @@ template <int NV> struct Solver {
     CMPC_TICK(20);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      const int rowi = lane + 64 * h;
+      const int rowi = lane + WS * h;
       const bool own = rowi >= C0 && rowi < NZ;
       double *wi = M + tri(own ? rowi : C0) + C0;
 #pragma unroll
       for (int c = 0; c < W; ++c) *((own && C0 + c <= rowi) ? wi + c : dump) = blk[h][c];
     }
-    CMPC_SYNC();
+    sync();
     CMPC_TICK(21);
     if (!trailing) return true;
     constexpr int R0 = C0 + W;                  // first trailing row / column
     constexpr int NBR = (NZ - R0 + 15) / 16;
-    const int r16 = lane & 15, kq = lane >> 4;
+    const int r16 = lane & 15, kq = (lane & 63) >> 4;
+    // two waves: the 16 x 16 tiles of the trailing triangle alternate between them
+    auto mine = [&](int rb, int cb) -> bool { return NW == 1 || ((rb * (rb + 1) / 2 + cb) & 1) == wv; };
     cmpc_v4d acc[NBR][NBR];
 #pragma unroll
     for (int rb = 0; rb < NBR; ++rb)
@@ -1038,7 +1079,8 @@ template <int NV> struct Solver {
 #pragma unroll
       for (int rb = 0; rb < NBR; ++rb)
 #pragma unroll
-        for (int cb = 0; cb <= rb; ++cb) acc[rb][cb] = CMPC_MFMA_F64(a[rb], a[cb], acc[rb][cb]);
+        for (int cb = 0; cb <= rb; ++cb)
+          if (mine(rb, cb)) acc[rb][cb] = CMPC_MFMA_F64(a[rb], a[cb], acc[rb][cb]);
     }
     CMPC_TICK(22);
     double *pm[NBR][NBR][4];
@@ -1050,7 +1092,7 @@ template <int NV> struct Solver {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = R0 + 16 * rb + kq + 4 * r, j = R0 + 16 * cb + r16;   // D row / column of this component
-          pm[rb][cb][r] = (i < NZ && j <= i) ? M + tri(i) + j : dump;
+          pm[rb][cb][r] = (i < NZ && j <= i && mine(rb, cb)) ? M + tri(i) + j : dump;
           old[rb][cb][r] = *pm[rb][cb][r];
         }
     if constexpr (R0 == NU) {
@@ -1063,7 +1105,7 @@ template <int NV> struct Solver {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = 16 * rb + kq + 4 * r, j = 16 * cb + r16;
-            const bool in = (i < NXA && j <= i);
+            const bool in = (i < NXA && j <= i && mine(rb, cb));
             const double v = old[rb][cb][r] - acc[rb][cb][r];
             *(in ? &L(D::oP + i * D::PS + j) : dump) = v;
             *(in ? &L(D::oP + j * D::PS + i) : dump) = v;
@@ -1077,7 +1119,7 @@ template <int NV> struct Solver {
 #pragma unroll
           for (int r = 0; r < 4; ++r) *pm[rb][cb][r] = old[rb][cb][r] - acc[rb][cb][r];
     }
-    CMPC_SYNC();
+    sync();
     return true;
   }
 
@@ -1104,17 +1146,17 @@ template <int NV> struct Solver {
     constexpr int NPAIR = D::NTRI / 2, CH = 16;            // pairs; passes per batch of loads
     const cmpc_v2d *src = reinterpret_cast<const cmpc_v2d *>(&L(D::oM));
 #pragma unroll 1
-    for (int q0 = 0; q0 * 64 < NPAIR; q0 += CH) {
+    for (int q0 = 0; q0 * WS < NPAIR; q0 += CH) {
       cmpc_v2d v[CH];
 #pragma unroll
       for (int q = 0; q < CH; ++q) {             // all LDS reads first; the tail is clamped (duplicate stores of the last pair)
-        const int e = lane + 64 * (q0 + q);
+        const int e = lane + WS * (q0 + q);
         v[q] = src[(e < NPAIR) ? e : NPAIR - 1];
       }
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
-        const int e = lane + 64 * (q0 + q);
-        if (64 * (q0 + q) < NPAIR) st.pair(D::gM / 2 + ((e < NPAIR) ? e : NPAIR - 1)) = v[q];
+        const int e = lane + WS * (q0 + q);
+        if (WS * (q0 + q) < NPAIR) st.pair(D::gM / 2 + ((e < NPAIR) ? e : NPAIR - 1)) = v[q];
       }
     }
   }
@@ -1135,7 +1177,7 @@ template <int NV> struct Solver {
     // m = h + [B A]'(.)   (scratch: TV for the mu^0 part, AL for the mu^1 part; both dead here)
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      const int col = lane + 64 * h;
+      const int col = lane + WS * h;
       if (col >= NZ) continue;
       double a0 = L(D::oH0 + col), a1 = L(D::oH1 + col);
 #pragma unroll
@@ -1145,12 +1187,12 @@ template <int NV> struct Solver {
       }
       L(D::oTV + col) = a0; L(D::oAL + col) = a1;
     }
-    CMPC_SYNC();
+    sync();
     CMPC_TICK(2);
     static_assert(NU % 2 == 0 && (NU / 2 == 16 || NU / 2 == 28), "half rows match the LDS batch-read helpers");
     constexpr int HB = NU / 2;
     double lf0, lf1;                           // l of this lane's row (lanes < NU)
-    {                                          // l = L^-1 m_u for both right-hand sides at once
+    if (first_wave()) {                        // l = L^-1 m_u for both right-hand sides at once
       const int li = (lane < NU) ? lane : NU - 1;
       double m0 = L(D::oTV + li), m1 = L(D::oAL + li);
       const double dinv = 1.0 / M[tri(li) + li];
@@ -1172,9 +1214,9 @@ template <int NV> struct Solver {
         L(D::oTV + lane) = lf0; L(D::oAL + lane) = lf1;   // handed to the next step at wave-uniform LDS addresses
       }
     }
-    CMPC_SYNC();
+    sync();
     CMPC_TICK(3);
-    {                                          // p = m_x - Ls l
+    if (first_wave()) {                        // p = m_x - Ls l
       const int lx = (lane < NXA) ? lane : 0;
       const double *l0 = &L(D::oTV), *l1 = &L(D::oAL);
       double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
@@ -1206,7 +1248,7 @@ template <int NV> struct Solver {
         st[D::gPV + lane] = p0; st[D::gPV1 + lane] = p1;
       }
     }
-    CMPC_SYNC();
+    sync();
   }
 
   struct Err { double e_d, e_p, e_c, e_cmu, sum_mult; int n_mult; };
@@ -1231,16 +1273,16 @@ template <int NV> struct Solver {
       if (k < N) {
         stage_geometry(k);
       } else {
-        for (int c = lane; c < 3 * NZ; c += 64) L(D::oGH + c) = 0.0;
+        for (int c = lane; c < 3 * NZ; c += WS) L(D::oGH + c) = 0.0;
         if (lane < NXA) L(D::oBV + lane) = 0.0;
-        CMPC_SYNC();
+        sync();
       }
       CMPC_TICK(11);
       stage_ineq(k, x0n2);
       CMPC_TICK(12);
       // barrier weights (W2 holds the activity flag on entry); on the very first sweep the slacks and
       // multipliers are created here: s = max(-g, 1e-2), z = mu / s
-      for (int r = lane; r < NI; r += 64) {
+      for (int r = lane; r < NI; r += WS) {
         const bool act = L(D::oW2 + r) != 0.0;
         const double g = L(D::oGK + r);
         double s = L(D::oSK + r), z = L(D::oZK + r);
@@ -1266,7 +1308,7 @@ template <int NV> struct Solver {
       }
       if (k < N && lane < NXA) er.e_p = fmax(er.e_p, fabs(L(D::oBV + lane)));
       if (k >= 1 && lane < NXA) { er.sum_mult += fabs(L(D::oLAMK + lane)); er.n_mult += 1; }
-      CMPC_SYNC();
+      sync();
       CMPC_TICK(25);
       // Hessian rows first: the column lists of [B A] (18 registers per lane) are not live across them
       CMPC_RELANE(lane); CMPC_OPAQUE(lane);
@@ -1277,7 +1319,7 @@ template <int NV> struct Solver {
       const GArr st = stage(k);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        const int col = lane + 64 * h;
+        const int col = lane + WS * h;
         if (col >= NZ) continue;
         const double ho = cost_grad(k, col, wz);
         double jw[3];
@@ -1294,12 +1336,12 @@ template <int NV> struct Solver {
       CMPC_TICK(26);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        const int c = lane + 64 * h;
+        const int c = lane + WS * h;
         if (c < NZ) { st[D::gGH + c] = L(D::oGH + c); st[D::gGH + D::GHS + c] = L(D::oGH + NZ + c); st[D::gGH + 2 * D::GHS + c] = L(D::oGH + 2 * NZ + c); }
       }
-      for (int r = lane; r < NI; r += 64) st[D::gG + r] = L(D::oGK + r);
+      for (int r = lane; r < NI; r += WS) st[D::gG + r] = L(D::oGK + r);
       CMPC_TICK(0);
-      CMPC_SYNC();
+      sync();
       if (k < N) {
         // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG
         if (lane < NXA) {
@@ -1313,7 +1355,7 @@ template <int NV> struct Solver {
           L(D::oXN1 + lane) = L(D::oPC + lane) + a;       // v0 = p0_{k+1} + P_{k+1} b
           st[D::gB + lane] = L(D::oBV + lane);
         }
-        CMPC_SYNC();                            // the T tile of add_GtPG aliases BV and the other stage vectors
+        sync();                            // the T tile of add_GtPG aliases BV and the other stage vectors
         CMPC_TICK(13);
         CMPC_RELANE(lane); CMPC_OPAQUE(lane);
         add_GtPG();
@@ -1329,36 +1371,46 @@ template <int NV> struct Solver {
           L(D::oPC + lane) = p0; L(D::oPC1 + lane) = p1;
           st[D::gPV + lane] = p0; st[D::gPV1 + lane] = p1;
         }
-        for (int e = lane; e < NXA * NXA; e += 64) {
+        for (int e = lane; e < NXA * NXA; e += WS) {
           const int i = e / NXA, c = e % NXA;
           const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
           L(D::oP + i * D::PS + c) = L(D::oM + tri(NU + hi) + NU + lo);
         }
-        CMPC_SYNC();
+        sync();
       }
       CMPC_RELANE(lane); CMPC_OPAQUE(lane);
       store_factors(k);
-      CMPC_SYNC();
+      sync();
       CMPC_TICK(4);
     }
     return true;
   }
 
-  // wave-wide reductions: six butterfly steps, no LDS
+  // reductions over the instance's lanes: six butterfly steps inside a wave, no LDS; with two waves the
+  // wave results meet in two LDS words (oCOLD + 4 / + 5) between two workgroup barriers
+  enum { OP_MAX = 0, OP_MIN = 1, OP_SUM = 2 };
+  CMPC_DEV double across_waves(double v, int op) {
+    if constexpr (NW == 1) return v;
+    if ((lane & 63) == 0) L(D::oCOLD + 4 + wv) = v;
+    sync();
+    const double a = L(D::oCOLD + 4), b = L(D::oCOLD + 5);
+    sync();
+    return (op == OP_MAX) ? fmax(a, b) : (op == OP_MIN) ? fmin(a, b) : a + b;
+  }
   CMPC_DEV double red_max(double v) {
 #pragma unroll 1
     for (int m = 32; m >= 1; m >>= 1) v = fmax(v, CMPC_XOR(v, m));
-    return v;
+    return across_waves(v, OP_MAX);
   }
   CMPC_DEV double red_min(double v) {
 #pragma unroll 1
     for (int m = 32; m >= 1; m >>= 1) v = fmin(v, CMPC_XOR(v, m));
-    return v;
+    return across_waves(v, OP_MIN);
   }
   CMPC_DEV double red_sum(double v) {
 #pragma unroll 1
     for (int m = 32; m >= 1; m >>= 1) v += CMPC_XOR(v, m);
-    return v;
+    return across_waves(v, OP_SUM);
   }
 
   // ---------------------------------------------------------------------------------------
@@ -1370,7 +1422,7 @@ template <int NV> struct Solver {
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void vector_sweeps(double mu, double dmu, double &ap, double &ad) {
     const double m = rec[20], muf = rec[21];
-    constexpr int NIH = (NI + 63) / 64;
+    constexpr int NIH = (NI + WS - 1) / WS;
     const double tau = fmax(0.99, 1 - mu);
     double lap = 1.0, lad = 1.0;
     constexpr bool MERGE = D::W_MERGE;
@@ -1380,7 +1432,7 @@ template <int NV> struct Solver {
     CMPC_SYNC_GLOBAL();                       // the slab was written with another lane mapping
     int cur = D::oXK, nxt = D::oXN1;          // dx_k / dx_{k+1} ping-pong
     if (lane < NXA) { L(cur + lane) = 0.0; gdx[lane] = 0.0; }
-    CMPC_SYNC();
+    sync();
     for (int k = 0; k <= N; ++k) {
       CMPC_RELANE(lane); CMPC_OPAQUE(lane);
       const GArr st = stage(k);
@@ -1390,16 +1442,16 @@ template <int NV> struct Solver {
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int h = 0; h < NH; ++h) gh[r][h] = st[D::gGH + r * D::GHS + lane + 64 * h];
+        for (int h = 0; h < NH; ++h) gh[r][h] = st[D::gGH + r * D::GHS + lane + WS * h];
       // contact flags of the stage (terminal node: header words 22, 23)
       const double gl = rec[(k < N) ? 24 + 19 * k + 17 : 22], gr = rec[(k < N) ? 24 + 19 * k + 18 : 23];
       // slack / multiplier directions of the stage are formed here too (one pass over the stages less)
       double al[NH], sv[NIH], zv[NIH], gv[NIH];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) { const int c = lane + 64 * h; al[h] = st[D::gAL + ((c < NZ) ? c : 0)]; }
+      for (int h = 0; h < NH; ++h) { const int c = lane + WS * h; al[h] = st[D::gAL + ((c < NZ) ? c : 0)]; }
 #pragma unroll
       for (int h = 0; h < NIH; ++h) {
-        const int r = lane + 64 * h, rc = (r < NI) ? r : 0;
+        const int r = lane + WS * h, rc = (r < NI) ? r : 0;
         sv[h] = gsl[k * NI + rc]; zv[h] = gz[k * NI + rc]; gv[h] = st[D::gG + rc];
       }
       const double hw0 = gx[k * NXA + 6], hw1 = gx[k * NXA + 7], hw2 = gx[k * NXA + 8];
@@ -1453,7 +1505,7 @@ template <int NV> struct Solver {
       auto slack_dirs = [&](double ldot) {     // ds, dz and the fraction-to-the-boundary bounds of stage k
 #pragma unroll
         for (int h = 0; h < NIH; ++h) {
-          const int r = lane + 64 * h;
+          const int r = lane + WS * h;
           if (r < NI) {
             const double sr_ = sv[h], zr = zv[h], gr_ = gv[h];
             double ds = 0.0, dz = 0.0;
@@ -1471,15 +1523,15 @@ template <int NV> struct Solver {
         double part = 0.0;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-          const int c = lane + 64 * h;
+          const int c = lane + WS * h;
           if (c >= NU && c < NZ) part += al[h] * L(cur + c - NU);
         }
         slack_dirs(red_sum(part));
-        CMPC_SYNC();                           // the caller reuses the stage vectors
+        sync();                           // the caller reuses the stage vectors
         break;
       }
-      double duv;
-      {                                        // L' du = -(l + Ls' dx), multipliers by readlane
+      double duv = 0.0;
+      if (first_wave()) {                      // L' du = -(l + Ls' dx), multipliers by readlane
         double treg = isA ? -(l0v + dmu * l1v + accA) : 0.0;
         const double dinv = 1.0 / dg;
 #pragma unroll
@@ -1494,14 +1546,28 @@ template <int NV> struct Solver {
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // s3: Lyapunov gradient . (du, dx)
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        const int c = lane + 64 * h;
+        const int c = lane + WS * h;
         const bool in = c < NZ;                // the row padding in the slab is never written
         const double z = (c < NU) ? duv : (in ? L(cur + c - NU) : 0.0);
         s0 += in ? gh[0][h] * z : 0.0; s1 += in ? gh[1][h] * z : 0.0; s2 += in ? gh[2][h] * z : 0.0;
         s3 += in ? al[h] * z : 0.0;
       }
-      s0 = red_sum(s0); s1 = red_sum(s1); s2 = red_sum(s2); s3 = red_sum(s3);
-      CMPC_SYNC();
+      if constexpr (NW == 1) {
+        s0 = red_sum(s0); s1 = red_sum(s1); s2 = red_sum(s2); s3 = red_sum(s3);
+      } else {                                 // the four sums cross the waves in one exchange
+#pragma unroll 1
+        for (int mm = 32; mm >= 1; mm >>= 1) {
+          s0 += CMPC_XOR(s0, mm); s1 += CMPC_XOR(s1, mm); s2 += CMPC_XOR(s2, mm); s3 += CMPC_XOR(s3, mm);
+        }
+        if ((lane & 63) == 0) {
+          double *w = &L(wv == 0 ? D::oRED : D::oCOLD + 4);
+          w[0] = s0; w[1] = s1; w[2] = s2; w[3] = s3;
+        }
+        sync();
+        s0 = L(D::oRED) + L(D::oCOLD + 4); s1 = L(D::oRED + 1) + L(D::oCOLD + 5);
+        s2 = L(D::oRED + 2) + L(D::oCOLD + 6); s3 = L(D::oRED + 3) + L(D::oCOLD + 7);
+      }
+      sync();
       slack_dirs(s3);
       CMPC_TICK(17);
       // dx+ = b + [B A] (du, dx)
@@ -1525,7 +1591,7 @@ template <int NV> struct Solver {
         gdx[(k + 1) * NXA + q] = a;
         L(nxt + q) = a;
       }
-      CMPC_SYNC();
+      sync();
       { const int t = cur; cur = nxt; nxt = t; }
       CMPC_TICK(18);
     }
@@ -1556,42 +1622,42 @@ template <int NV> struct Solver {
     CMPC_SYNC_GLOBAL();                       // directions were written with a per-stage lane mapping
     // elementwise updates, four independent load groups in flight per pass
     constexpr int UF = 4;
-    for (int e0 = NXA; e0 < (N + 1) * NXA; e0 += 64 * UF) {
+    for (int e0 = NXA; e0 < (N + 1) * NXA; e0 += WS * UF) {
       double a[UF], b[UF], c[UF], d[UF];
 #pragma unroll
       for (int q = 0; q < UF; ++q) {
-        const int e = e0 + lane + 64 * q, ec = (e < (N + 1) * NXA) ? e : NXA;
+        const int e = e0 + lane + WS * q, ec = (e < (N + 1) * NXA) ? e : NXA;
         a[q] = gx[ec]; b[q] = gdx[ec]; c[q] = glam[ec]; d[q] = glamn[ec];
       }
 #pragma unroll
       for (int q = 0; q < UF; ++q) {
-        const int e = e0 + lane + 64 * q;
+        const int e = e0 + lane + WS * q;
         if (e < (N + 1) * NXA) { gx[e] = a[q] + ap * b[q]; glam[e] = c[q] + ap * (d[q] - c[q]); }
       }
     }
-    for (int e0 = 0; e0 < N * NU; e0 += 64 * UF) {
+    for (int e0 = 0; e0 < N * NU; e0 += WS * UF) {
       double a[UF], b[UF];
 #pragma unroll
       for (int q = 0; q < UF; ++q) {
-        const int e = e0 + lane + 64 * q, ec = (e < N * NU) ? e : 0;
+        const int e = e0 + lane + WS * q, ec = (e < N * NU) ? e : 0;
         a[q] = gu[ec]; b[q] = gdu[ec];
       }
 #pragma unroll
       for (int q = 0; q < UF; ++q) {
-        const int e = e0 + lane + 64 * q;
+        const int e = e0 + lane + WS * q;
         if (e < N * NU) gu[e] = a[q] + ap * b[q];
       }
     }
-    for (int e0 = 0; e0 < (N + 1) * NI; e0 += 64 * UF) {
+    for (int e0 = 0; e0 < (N + 1) * NI; e0 += WS * UF) {
       double zq[UF], sq[UF], dsq[UF], dzq[UF];
 #pragma unroll
       for (int q = 0; q < UF; ++q) {
-        const int e = e0 + lane + 64 * q, ec = (e < (N + 1) * NI) ? e : 0;
+        const int e = e0 + lane + WS * q, ec = (e < (N + 1) * NI) ? e : 0;
         zq[q] = gz[ec]; sq[q] = gsl[ec]; dsq[q] = gds[ec]; dzq[q] = gdz[ec];
       }
 #pragma unroll
       for (int q = 0; q < UF; ++q) {
-        const int e = e0 + lane + 64 * q;
+        const int e = e0 + lane + WS * q;
         if (e < (N + 1) * NI && zq[q] != 0.0) {
           const double s = sq[q] + ap * dsq[q];
           const double z = zq[q] + ad * dzq[q];
@@ -1613,7 +1679,7 @@ template <int NV> struct Solver {
     // Source stage of every stage (see the oracle): stage k resumes from the state's stage k, or from its stage k + 1
     // where a contact switch has moved one stage closer since the state was written.  Table in LDS (M is free here).
     double *srct = &L(D::oM);
-    for (int k = lane; k <= N; k += 64) {
+    for (int k = lane; k <= N; k += WS) {
       int src = k;
       if (resume) {
         const double gl = rec[(k < N) ? 24 + 19 * k + 17 : 22], gr = rec[(k < N) ? 24 + 19 * k + 18 : 23];
@@ -1624,14 +1690,14 @@ template <int NV> struct Solver {
       }
       srct[k] = (double)src;
     }
-    CMPC_SYNC();
-    for (int e = lane; e < (N + 1) * NXA; e += 64) {
+    sync();
+    for (int e = lane; e < (N + 1) * NXA; e += WS) {
       const int k = e / NXA, i = e % NXA, ks = (int)srct[k];
       double v = 0.0;
       if (i < CMPC_NX) v = (has_warm && k >= 1) ? warm[ks * CMPC_NX + i] : rec[i];
       gx[e] = v; glam[e] = resume ? st_in[D::state_lam(N) + ks * NXA + i] : 0.0;
     }
-    for (int e = lane; e < N * NU; e += 64) {
+    for (int e = lane; e < N * NU; e += WS) {
       const int k = e / NU, i = e % NU, ks = ((int)srct[k] < N) ? (int)srct[k] : N - 1;
       double v = 0.0, up = has_prox ? prox[CMPC_NX * (N + 1) + e] : 0.0;
       if (has_warm) { v = warm[CMPC_NX * (N + 1) + ks * NU + i]; }
@@ -1642,13 +1708,13 @@ template <int NV> struct Solver {
       gu[e] = v; gupx[e] = up;
     }
     // slacks / multipliers of the solver state (zeros = none: the first sweep creates them by the cold rule)
-    for (int e = lane; e < (N + 1) * NI; e += 64) {
+    for (int e = lane; e < (N + 1) * NI; e += WS) {
       const int k = e / NI, i = e % NI, ks = (int)srct[k];
       gsl[e] = resume ? st_in[D::state_s(N) + ks * NI + i] : 0.0;
       gz[e] = resume ? st_in[D::state_z(N) + ks * NI + i] : 0.0;
     }
     CMPC_SYNC_GLOBAL();
-    for (int e = lane; e < N * NF; e += 64) {
+    for (int e = lane; e < N * NF; e += WS) {
       const int k = e / NF + 1, j = e % NF;
       gx[k * NXA + CMPC_NX + j] = gu[(k - 1) * NU + 3 * j + 2];
     }
@@ -1659,8 +1725,8 @@ template <int NV> struct Solver {
   // initial_point left them (both end with a full fence).
   CMPC_DEV void write_solution(double *out_) {
     const GArr out{out_};
-    for (int e = lane; e < (N + 1) * CMPC_NX; e += 64) out[e] = gx[(e / CMPC_NX) * NXA + (e % CMPC_NX)];
-    for (int e = lane; e < N * NU; e += 64) out[CMPC_NX * (N + 1) + e] = gu[e];
+    for (int e = lane; e < (N + 1) * CMPC_NX; e += WS) out[e] = gx[(e / CMPC_NX) * NXA + (e % CMPC_NX)];
+    for (int e = lane; e < N * NU; e += WS) out[CMPC_NX * (N + 1) + e] = gu[e];
   }
 
   // Solver state for the next tick (CMPC_NSTATE, include/cmpc.h): the current iterate, labelled with its barrier value.
@@ -1668,14 +1734,14 @@ template <int NV> struct Solver {
     const GArr so{state_out};
     CMPC_SYNC_GLOBAL();                         // (first iteration: the slacks were written by the sweep's lane mapping)
     write_solution(state_out);
-    for (int e = lane; e < (N + 1) * NXA; e += 64) so[D::state_lam(N) + e] = glam[e];
-    for (int e = lane; e < (N + 1) * NI; e += 64) { so[D::state_s(N) + e] = gsl[e]; so[D::state_z(N) + e] = gz[e]; }
-    for (int k = lane; k <= N; k += 64) {
+    for (int e = lane; e < (N + 1) * NXA; e += WS) so[D::state_lam(N) + e] = glam[e];
+    for (int e = lane; e < (N + 1) * NI; e += WS) { so[D::state_s(N) + e] = gsl[e]; so[D::state_z(N) + e] = gz[e]; }
+    for (int k = lane; k <= N; k += WS) {
       so[D::state_fl(N) + k] = rec[(k < N) ? 24 + 19 * k + 17 : 22];
       so[D::state_fl(N) + N + 1 + k] = rec[(k < N) ? 24 + 19 * k + 18 : 23];
     }
     if (lane == 0) so[D::state_mu(N)] = mu_level;
-    CMPC_SYNC();                                // (host emulation: every lane has read the flag the caller sets next)
+    sync();                                // (host emulation: every lane has read the flag the caller sets next)
   }
 
   // ---------------------------------------------------------------------------------------
@@ -1722,7 +1788,7 @@ template <int NV> struct Solver {
       const double mu_sweep = mu;               // barrier value the sweep's gradients are formed at
       const double rl = reg_last;               // (cold state: read once, ahead of the fences of the sweep)
       while (!matrix_sweep(mu, reg, x0n2, er, it == 0)) {
-        CMPC_SYNC();
+        sync();
         if (reg == 0.0) reg = (rl == 0.0) ? 1e-4 : fmax(1e-20, rl / 3);
         else reg *= (rl == 0.0) ? 100.0 : 8.0;
         if (reg > 1e20) { fail = true; break; }
@@ -1737,7 +1803,7 @@ template <int NV> struct Solver {
         printf("it %3d d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e\n", it, e_d / sd, e_p, e_c / sd, mu, reg);
 #endif
       double ks = kkt_saved, kb = kkt_best;     // cold state: every lane reads before any lane writes
-      CMPC_SYNC();
+      sync();
       if (polish >= 0 && kkt > ACC_FACTOR * tol) {
         // polishing lost ground (the step at the final barrier value needed an inertia correction): the point
         // that met the tolerance was written to `out` before the polish and is what is returned
@@ -1794,7 +1860,7 @@ template <int NV> struct Solver {
     if (lane == 0 && ka.prof)
       for (int i = 0; i < 28; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);
 #endif
-    CMPC_SYNC();
+    sync();
   }
 };
 

@@ -61,6 +61,21 @@ def test_kernel_source_eight_vertex_patch(emu, oracle):
     assert rel_inf(got, ref).max() < 1e-9
 
 
+@pytest.mark.parametrize("waves", ["1", "2"])
+def test_kernel_source_eight_vertex_one_and_two_waves(emu, oracle, monkeypatch, waves):
+    """The 8-vertex solver as one wave and as the two-wave workgroup the product launches (pivot chains in the first
+    wave, rows 64.. of the stage block in the second, trailing tiles alternating), LDS and slab pre-filled with NaN,
+    two instances so that slab reuse is covered."""
+    monkeypatch.setenv("CMPC_EMU_FILL", "nan")
+    monkeypatch.setenv("CMPC_EMU_WAVES", waves)
+    spec, rec = wl.make_workload("long_horizon", B=2, N=5)
+    cs = oracle_spec(oracle, spec)
+    got, st, it, kk = _emu_solve(emu, cs, rec)
+    ref, st_ref, it_ref, _ = oracle.solve_batch(cs, rec)
+    assert (st == 0).all() and (st_ref == 0).all() and np.abs(it - it_ref).max() <= 1
+    assert rel_inf(got, ref).max() < 3e-5           # 8-vertex force split: flat valley (tests/test_independent_pins.py)
+
+
 def test_kernel_source_warm_start_and_garbage_memory(emu, oracle, monkeypatch):
     """Warm start path; LDS and scratch pre-filled with NaN (no read of uninitialised memory)."""
     monkeypatch.setenv("CMPC_EMU_FILL", "nan")
