@@ -473,15 +473,15 @@ template <int NV, int NW = 1> struct Solver {
 
   // Column list of [B A] for this lane's column (lane < NZ): id, 3 h-rows, 2 specials.
   CMPC_DEV void build_list(const double *gh, double gl, double gr, double m) {
-    const double d = sp.delta;
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      int *r = lr[h];
-      double *g = lg[h];
+    for (int h = 0; h < NH; ++h) column_list(lane + WS * h, lr[h], lg[h], gh, gl, gr, m);
+  }
+  CMPC_DEV void column_list(const int col, int *r, double *g, const double *gh, double gl, double gr, double m) const {
+    const double d = sp.delta;
+    {
 #pragma unroll
       for (int n = 0; n < 6; ++n) { r[n] = 0; g[n] = 0.0; }
-      const int col = lane + WS * h;
-      if (col >= NZ) continue;
+      if (col >= NZ) return;
       r[1] = 6; r[2] = 7; r[3] = 8;
       g[1] = gh[col]; g[2] = gh[NZ + col]; g[3] = gh[2 * NZ + col];
       if (col < 6 * NV) {
@@ -836,7 +836,7 @@ template <int NV, int NW = 1> struct Solver {
   }
 
   // M += [B A]' P [B A]  (lower triangle, row owner), using T = P [B A] staged by column halves.
-  CMPC_DEV void add_GtPG() {
+  CMPC_DEV void add_GtPG(double gl, double gr, double m) {
     // Register-blocked in small tiles: within a tile every LDS read is independent of the others (one
     // wave per SIMD has nothing else to hide the ~100-cycle LDS latency behind), and the tiles are
     // small enough (<= 2 x 14 doubles live) that the allocator does not serialise the reads.
@@ -846,30 +846,44 @@ template <int NV, int NW = 1> struct Solver {
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       const int c0 = half * D::TH, c1 = (c0 + D::TH < NZ) ? c0 + D::TH : NZ;
+      auto t_rows = [&](const int col, const int q0, const int *cr, const double *cg) {   // T[q0 .. q0+QT)[col]
+        double acc[QT];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {           // column of T = P [B A] owned by this lane in this half
-        const int col = lane + WS * h;
-        if (col >= c0 && col < c1) {
+        for (int q = 0; q < QT; ++q) acc[q] = 0.0;
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+          const double g = cg[n];
+          double v[QT];
+          const double *pc = &L(D::oP + q0 * D::PS + cr[n]);
+          if constexpr (QT == 28) lds_read_strided28<D::PS>(v, pc);
+          else if constexpr (QT == 18) lds_read_strided18<D::PS>(v, pc);
+          else lds_read_strided14<D::PS>(v, pc);
+#pragma unroll
+          for (int q = 0; q < QT; ++q) acc[q] += g * v[q];
+        }
+        double *tc = &L(D::oT + q0 * D::TS + (col - c0));
+#pragma unroll
+        for (int q = 0; q < QT; ++q) tc[q * D::TS] = acc[q];
+      };
+      if constexpr (NW == 1) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {         // column of T = P [B A] owned by this lane in this half
+          const int col = lane + WS * h;
+          if (col >= c0 && col < c1) {
 #pragma unroll 1
-          for (int q0 = 0; q0 < NXA; q0 += QT) {
-            double acc[QT];
-#pragma unroll
-            for (int q = 0; q < QT; ++q) acc[q] = 0.0;
-#pragma unroll
-            for (int n = 0; n < 6; ++n) {
-              const double g = lg[h][n];
-              double v[QT];
-              const double *pc = &L(D::oP + q0 * D::PS + lr[h][n]);
-              if constexpr (QT == 28) lds_read_strided28<D::PS>(v, pc);
-              else if constexpr (QT == 18) lds_read_strided18<D::PS>(v, pc);
-              else lds_read_strided14<D::PS>(v, pc);
-#pragma unroll
-              for (int q = 0; q < QT; ++q) acc[q] += g * v[q];
-            }
-            double *tc = &L(D::oT + q0 * D::TS + (col - c0));
-#pragma unroll
-            for (int q = 0; q < QT; ++q) tc[q * D::TS] = acc[q];
+            for (int q0 = 0; q0 < NXA; q0 += QT) t_rows(col, q0, lr[h], lg[h]);
           }
+        }
+      } else {
+        // two waves: lane l of either wave takes column c0 + l of the half, the first wave its upper QT rows and the
+        // second the lower ones; the column's list is rebuilt on the spot (the lane's own list is another column's)
+        static_assert(NW == 1 || (!D::T_ALIAS && D::TH <= 64 && NXA == 2 * QT), "T has its own tile; one lane per column and row half");
+        const int col = c0 + (lane & 63);
+        if (col < c1) {
+          int cr[6];
+          double cg[6];
+          column_list(col, cr, cg, &L(D::oGH), gl, gr, m);
+          t_rows(col, wv * QT, cr, cg);
         }
       }
       sync();
@@ -1358,7 +1372,7 @@ template <int NV, int NW = 1> struct Solver {
         sync();                            // the T tile of add_GtPG aliases BV and the other stage vectors
         CMPC_TICK(13);
         CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-        add_GtPG();
+        add_GtPG(L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
         CMPC_TICK(14);
         CMPC_RELANE(lane); CMPC_OPAQUE(lane);
         if (!factor_stage(k)) return false;

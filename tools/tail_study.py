@@ -1,0 +1,58 @@
+"""Developer script: how much of a launch is drain?  Solves a workload once, then replays the ticket queue on the host
+from the measured iteration counts: makespan (in instance-iterations) of the shipped order (contact-switch class first),
+of the input order and of longest-first with perfect knowledge, against the balanced bound sum / slots and the longest
+instance.  usage (GPU box): python tools/tail_study.py [workload] [B]"""
+import heapq, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import cmpc_amd
+from cmpc_amd import workloads as wl
+from cmpc_amd.solver import BatchedCentroidalMPC
+
+name = sys.argv[1] if len(sys.argv) > 1 else "long_horizon"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+spec, rec = wl.make_workload(name, B=B)
+if spec.N > 20:
+    spec.max_iter = 150
+s = BatchedCentroidalMPC(spec, device="cuda:0")
+d = torch.from_numpy(rec).to("cuda:0")
+s.solve(d); torch.cuda.synchronize()
+_, status, iters, _ = s.solve(d); torch.cuda.synchronize()
+ms = s.last_kernel_ms()
+it = iters.cpu().numpy().astype(np.int64); st = status.cpu().numpy()
+N = spec.N
+fl = np.stack([rec[:, 24 + 19 * np.arange(N) + 17], rec[:, 24 + 19 * np.arange(N) + 18]], -1)
+fl = np.concatenate([fl, rec[:, None, 22:24]], 1)
+sw = (np.diff(fl, axis=0 if fl.ndim == 1 else 1) != 0).any(axis=(1, 2))
+slots = min(B, 256 * (160 * 1024 // s.lds_bytes() if hasattr(s, "lds_bytes") else (5 if spec.nv == 4 else 2)))
+
+
+def makespan(order):
+    h = [0] * slots
+    heapq.heapify(h)
+    end = 0
+    for i in order:
+        t = heapq.heappop(h) + it[i]
+        end = max(end, t)
+        heapq.heappush(h, t)
+    return end
+
+
+idx = np.arange(B)
+shipped = np.concatenate([idx[sw], idx[~sw][::-1]])
+print(f"{name} B={B} N={N} nv={spec.nv}: kernel {ms:.1f} ms, slots {slots}, mean its {it.mean():.2f}, max {it.max()}, "
+      f"switch class {sw.mean():.2%}")
+print("iterations: quantiles 50/90/99/100 =", [int(np.quantile(it, q)) for q in (0.5, 0.9, 0.99, 1.0)])
+for cls, m in (("switch", sw), ("no switch", ~sw)):
+    if m.any():
+        print(f"  {cls:10s} n={m.sum():5d} mean {it[m].mean():6.2f} q99 {int(np.quantile(it[m], 0.99))} max {it[m].max()}")
+bal = it.sum() / slots
+print(f"balanced bound {bal:.1f} instance-iterations per slot; longest instance {it.max()}")
+for lab, o in (("input order", idx), ("shipped (switch class first)", shipped), ("longest first (perfect knowledge)", np.argsort(-it))):
+    mk = makespan(o)
+    print(f"  {lab:36s} makespan {mk:5d} = {mk / bal:.3f} x balanced")
+print(f"time per instance-iteration at the shipped makespan: {ms / makespan(shipped) * 1e3:.1f} us")
+by = {int(v): int((st == v).sum()) for v in np.unique(st)}
+print("status", by, " mean its by status", {int(v): round(float(it[st == v].mean()), 1) for v in np.unique(st)},
+      " max its by status", {int(v): int(it[st == v].max()) for v in np.unique(st)})
