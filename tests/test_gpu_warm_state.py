@@ -110,3 +110,31 @@ def test_state_edge_cases_stale_state_nan_record_and_horizon_limits(oracle):
         # hovers at ~1e-8 for as long as it is allowed to, resumed or not (oracle: cold 43 iterations "acceptable", the
         # same tolerance-level point): only the outcome is asserted there
         assert N == 64 or int(it_y[0]) < int(it_x[0])
+
+
+def test_state_path_of_the_eight_vertex_two_wave_kernel(oracle):
+    """The 8-vertex solver (two waves per instance) through the state entry point: an empty state is the plain solve
+    bit for bit, a resumed re-solve of every instance reaches the same optimum as the oracle's resumed solve in a
+    fraction of the iterations, and a batch larger than the resident grid (512 workgroups) is the sum of its
+    instances."""
+    spec, rec = wl.make_workload("long_horizon", B=640, N=10)
+    solver = BatchedCentroidalMPC(spec, device="cuda:0")
+    cs = oracle_spec(oracle, spec)
+    d = torch.from_numpy(rec).cuda()
+    s1, s2 = solver.new_state(640), solver.new_state(640)
+    a, st_a, it_a, _ = solver.solve(d)
+    b, st_b, it_b, _ = solver.solve(d, state=s1, state_out=s2)
+    assert torch.equal(a, b) and torch.equal(it_a, it_b) and torch.equal(st_a, st_b)
+    c, st_c, it_c, _ = solver.solve(d, warm=b, state=s2, state_out=s1)
+    ok = ((st_b == 0) & (st_c == 0)).cpu().numpy()
+    assert ok.mean() > 0.85 and it_c.cpu().numpy()[ok].mean() < 0.6 * it_b.cpu().numpy()[ok].mean()
+    # the oracle from the kernel's own state and solution (first 24 instances)
+    n = 24
+    out_o, _, st_o, it_o, _ = oracle.solve_batch_state(cs, rec[:n], warm=b[:n].cpu().numpy(), state=s2[:n].cpu().numpy())
+    both = ok[:n] & (st_o == 0)
+    assert both.sum() >= 16
+    assert np.median(rel_inf(c[:n].cpu().numpy()[both], out_o[both])) < 1e-7
+    assert np.abs(it_c[:n].cpu().numpy()[both] - it_o[both]).max() <= 4
+    for i in (0, 333, 639):
+        ci, _, it_i, _ = solver.solve(d[i:i + 1], warm=b[i:i + 1], state=s2[i:i + 1].clone(), state_out=solver.new_state(1))
+        assert torch.equal(ci[0], c[i]) and int(it_i[0]) == int(it_c[i])
