@@ -162,7 +162,10 @@ template <int NV, int NW = 1> struct Dims {
   static constexpr int NH = (NZ + WS - 1) / WS;   // rows / columns of the stage block owned by one lane
   static constexpr int PS = NXA + 1;          // odd row strides: conflict-free column access
   static constexpr int LS = NU + 1;
-  static constexpr int TH = (NZ + 1) / 2;     // columns per half of T = P [B A]
+  // T = P [B A] is staged in NPART column parts.  One wave, 60 columns: three parts of 20 columns, and the lanes of the
+  // wave are (column of the part) x (row third), so that all 64 lanes work on every part; otherwise halves.
+  static constexpr int NPART = (NV == 4 && NW == 1) ? 3 : 2;
+  static constexpr int TH = (NZ + NPART - 1) / NPART;   // columns per part
   static constexpr int TS = TH | 1;
   // ---- LDS map (doubles) ----
   static constexpr int oM = 0;
@@ -203,7 +206,10 @@ template <int NV, int NW = 1> struct Dims {
   // [oSK, oTV + NZ) when it fits (nv = 4): all of them are dead between build_H and the next
   // stage's load.  Otherwise (nv = 8) it gets its own region.
   static constexpr bool T_ALIAS = (oSK + NXA * TS <= oTV + NZ);
-  static constexpr int oT = T_ALIAS ? oSK : oDUMP + WS;
+  // (three parts: the tile is 28 x 21 and must end before GH, which the parts' column lists are rebuilt from: it
+  // starts two words early, in the tail of lam_{k+1}, dead by then like the rest)
+  static constexpr int oT = T_ALIAS ? ((NPART == 3) ? oSK - 2 : oSK) : oDUMP + WS;
+  static_assert(!(T_ALIAS && NPART == 3) || oT + (NXA - 1) * TS + TH <= oGH, "the T tile ends before the dense rows of [B A]");
   // (+ T_PAD: add_GtPG reads the T rows in batches of 10 columns whatever the row's length; the tail of the
   // last row must still be inside the allocation)
   static constexpr int T_PAD = 10;
@@ -844,8 +850,34 @@ template <int NV, int NW = 1> struct Solver {
     static_assert(QT == 28 || QT == 18 || QT == 14, "LDS batch-read helper sizes");
     constexpr int CT = 10;                                      // columns of M per tile
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < D::NPART; ++half) {
       const int c0 = half * D::TH, c1 = (c0 + D::TH < NZ) ? c0 + D::TH : NZ;
+      if constexpr (D::NPART == 3) {
+        // lane = (column of the part, row third): rows 0..9, 10..19, 18..27 (the overlap is written twice with the
+        // same values); the column's list is rebuilt on the spot (the lane's own list is another column's)
+        static_assert(D::NPART != 3 || (3 * D::TH <= 64 && NXA == 28), "three row thirds of ten rows");
+        const int rs = (lane >= 2 * D::TH) ? 2 : (lane >= D::TH) ? 1 : 0;
+        const int col = c0 + lane - rs * D::TH, q0 = (rs == 2) ? NXA - 10 : 10 * rs;
+        if (lane < 3 * D::TH && col < c1) {
+          int cr[6];
+          double cg[6];
+          column_list(col, cr, cg, &L(D::oGH), gl, gr, m);
+          double acc[10];
+#pragma unroll
+          for (int q = 0; q < 10; ++q) acc[q] = 0.0;
+#pragma unroll
+          for (int n = 0; n < 6; ++n) {
+            const double g = cg[n];
+            double v[10];
+            lds_read_strided10<D::PS>(v, &L(D::oP + q0 * D::PS + cr[n]));
+#pragma unroll
+            for (int q = 0; q < 10; ++q) acc[q] += g * v[q];
+          }
+          double *tc = &L(D::oT + q0 * D::TS + (col - c0));
+#pragma unroll
+          for (int q = 0; q < 10; ++q) tc[q * D::TS] = acc[q];
+        }
+      }
       auto t_rows = [&](const int col, const int q0, const int *cr, const double *cg) {   // T[q0 .. q0+QT)[col]
         double acc[QT];
 #pragma unroll
@@ -865,7 +897,8 @@ template <int NV, int NW = 1> struct Solver {
 #pragma unroll
         for (int q = 0; q < QT; ++q) tc[q * D::TS] = acc[q];
       };
-      if constexpr (NW == 1) {
+      if constexpr (D::NPART == 3) {
+      } else if constexpr (NW == 1) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {         // column of T = P [B A] owned by this lane in this half
           const int col = lane + WS * h;
