@@ -170,29 +170,19 @@ template <int NV, int NW = 1> struct Dims {
   // ---- LDS map (doubles) ----
   static constexpr int oM = 0;
   static constexpr int oP = oM + NTRI + (NTRI & 1);
-  static constexpr int oXK = oP + NXA * PS + ((NXA * PS) & 1);
-  static constexpr int oUK = oXK + NXA;
-  static constexpr int oXN1 = oUK + NU;
-  static constexpr int oLAMK = oXN1 + NXA;
-  static constexpr int oLAMN = oLAMK + NXA;
-  static constexpr int oSK = oLAMN + NXA;
-  static constexpr int oZK = oSK + NI;
-  static constexpr int oGK = oZK + NI;
-  static constexpr int oW0 = oGK + NI;        // sigma = z/s
-  static constexpr int oW1 = oW0 + NI;        // sigma*(g+s)
-  static constexpr int oW2 = oW1 + NI;        // 1/s
-  static constexpr int oVR = oW2 + NI;        // r_j   (NF x 3)
-  static constexpr int oVDV = oVR + 3 * NF;   // R' v_j
-  static constexpr int oVRV = oVDV + 3 * NF;  // R v_j
-  static constexpr int oMISC = oVRV + 3 * NF; // 64 scalars
-  static constexpr int oAL = oMISC + 64;      // Lyapunov gradient (NZ)
-  static constexpr int oHO = oAL + NZ;
-  static constexpr int oGH = oHO + NZ;        // rows 6..8 of [B A] without identity (3 x NZ)
-  static constexpr int oBV = oGH + 3 * NZ;
-  static constexpr int oPC = oBV + NXA;
-  static constexpr int oTV = oPC + NXA;       // NZ temp
-  static constexpr int oUPX = oTV + NZ;
-  static constexpr int oSR = oUPX + NU;       // stage record k (19), k-1 (19), header (24)
+  // P_{k+1}: the full symmetric array (row stride PS) or, for the one-wave 4-vertex solver, its packed lower triangle
+  // (406 words instead of 812: a column read then takes both candidate words of every element and a select)
+  static constexpr bool P_PACKED = (NV == 4 && NW == 1);
+  static constexpr int NPT = NXA * (NXA + 1) / 2;
+  static constexpr int P_DOUBLES = P_PACKED ? NPT + (NPT & 1) : NXA * PS + ((NXA * PS) & 1);
+  // After M and P: first what stays live from a stage's evaluation to its backward vectors, then the evaluation
+  // vectors in the order that lets the T tile (which aliases them where it fits) end before GH.  Sizes in the compact
+  // form (one-wave 4-vertex solver: six workgroups per CU need the whole image under 26 880 bytes) are exact.
+  static constexpr bool COMPACT = (NV == 4 && NW == 1);
+  static constexpr int DUMPN = COMPACT ? 16 : WS;              // write-only slots for masked-off stores (lane & (DUMPN - 1))
+  static constexpr int MISCN = COMPACT ? 52 : 64;              // scalars of the geometry / inequality phases (0 .. 49 used)
+  static constexpr int oXN1 = oP + P_DOUBLES;                  // v0 = p_{k+1} + P_{k+1} b
+  static constexpr int oSR = oXN1 + NXA;      // stage record k (19), k-1 (19), header (24)
   static constexpr int oSRP = oSR + 20;
   static constexpr int oHDR = oSRP + 20;
   static constexpr int oH0 = oHDR + 24;       // gradient parts h = h0 + mu*h1 of the stage (NZ each)
@@ -201,19 +191,41 @@ template <int NV, int NW = 1> struct Dims {
   static constexpr int oRED = oPC1 + NXA;     // 4 scratch slots
   static constexpr int oCOLD = oRED + 4;      // outer-loop state that is touched once per iteration (8 scalars): kept here
                                               // instead of in registers, where it was spilled to scratch
-  static constexpr int oDUMP = oCOLD + 8;     // one write-only slot per lane: target of masked-off read-modify-writes
-  // The staging tile of T = P [B A] (NXA x TS) aliases the per-stage evaluation vectors
-  // [oSK, oTV + NZ) when it fits (nv = 4): all of them are dead between build_H and the next
-  // stage's load.  Otherwise (nv = 8) it gets its own region.
-  static constexpr bool T_ALIAS = (oSK + NXA * TS <= oTV + NZ);
-  // (three parts: the tile is 28 x 21 and must end before GH, which the parts' column lists are rebuilt from: it
-  // starts two words early, in the tail of lam_{k+1}, dead by then like the rest)
-  static constexpr int oT = T_ALIAS ? ((NPART == 3) ? oSK - 2 : oSK) : oDUMP + WS;
-  static_assert(!(T_ALIAS && NPART == 3) || oT + (NXA - 1) * TS + TH <= oGH, "the T tile ends before the dense rows of [B A]");
+  static constexpr int oDUMP = oCOLD + 8;
+  // ---- evaluation vectors: dead from the end of the gradient (the P b product for BV / PC) to the next stage's load
+  static constexpr int oXK = oDUMP + DUMPN + ((oDUMP + DUMPN) & 1);
+  static constexpr int oUK = oXK + NXA;
+  static constexpr int oLAMK = oUK + NU;
+  static constexpr int oLAMN = oLAMK + NXA;
+  static constexpr int oUPX = oLAMN + NXA;
+  static constexpr int oSK = oUPX + NU;
+  static constexpr int oZK = oSK + NI;
+  static constexpr int oGK = oZK + NI;
+  static constexpr int oW0 = oGK + NI;        // sigma = z/s
+  static constexpr int oW1 = oW0 + NI;        // sigma*(g+s)
+  static constexpr int oW2 = oW1 + NI;        // 1/s
+  static constexpr int oVDV = oW2 + NI;       // R' v_j (NF x 3)
+  static constexpr int oMISC = oVDV + 3 * NF;
+  static constexpr int oAL = oMISC + MISCN;   // Lyapunov gradient (NZ); second temporary of the backward vectors
+  static constexpr int oGH = oAL + NZ;        // rows 6..8 of [B A] without identity (3 x NZ)
+  static constexpr int oBV = oGH + 3 * NZ;
+  static constexpr int oPC = oBV + NXA;
+  static constexpr int oEND = oPC + NXA;
+  // overlays: r_j (NF x 3) lives from the first to the third step of the geometry, in the words the inequality rows
+  // then fill with the Lyapunov gradient; the NZ-word temporary of the backward vectors takes the slacks' place
+  static constexpr int oVR = oAL;
+  static constexpr int oTV = oSK;
+  static_assert(3 * NF <= NZ && NZ <= 2 * NI, "overlays fit");
+  // The staging tile of T = P [B A] (NXA x TS): for nv = 4 it aliases the evaluation vectors from their start and ends
+  // before GH, which the parts' column lists are rebuilt from; for nv = 8 it gets its own region.
+  static constexpr bool T_ALIAS = (NV == 4);
+  static constexpr int oT = T_ALIAS ? oXK : oEND;
+  static_assert(!T_ALIAS || oT + (NXA - 1) * TS + TH <= oGH, "the T tile ends before the dense rows of [B A]");
+  static_assert(oT % 2 == 0, "16-byte reads of the in-block table");
   // (+ T_PAD: add_GtPG reads the T rows in batches of 10 columns whatever the row's length; the tail of the
   // last row must still be inside the allocation)
   static constexpr int T_PAD = 10;
-  static constexpr int LDS_DOUBLES = T_ALIAS ? oDUMP + WS : oDUMP + WS + NXA * TS + T_PAD;
+  static constexpr int LDS_DOUBLES = T_ALIAS ? oEND : oEND + NXA * TS + T_PAD;
   // ---- global scratch map per stage (doubles) ----
   // The factorised stage block as it stands in LDS, a packed lower triangle of NZ rows, copied word for word:
   // rows 0..NU-1 hold Lambda, row NU+c holds [Ls row c | P_k row c up to the diagonal].  (Round 2 wrote Lambda as a
@@ -390,7 +402,6 @@ template <int NV, int NW = 1> struct Solver {
       const double rvx = cs * vx - sn * vy, rvy = sn * vx + cs * vy;
       const double dvx = -sn * vx - cs * vy, dvy = cs * vx - sn * vy;
       const double rx = px + rvx - cx, ry = py + rvy - cy, rz = pz - cz;
-      L(D::oVRV + 3 * lane + 0) = rvx; L(D::oVRV + 3 * lane + 1) = rvy; L(D::oVRV + 3 * lane + 2) = 0.0;
       L(D::oVDV + 3 * lane + 0) = dvx; L(D::oVDV + 3 * lane + 1) = dvy; L(D::oVDV + 3 * lane + 2) = 0.0;
       L(D::oVR + 3 * lane + 0) = rx; L(D::oVR + 3 * lane + 1) = ry; L(D::oVR + 3 * lane + 2) = rz;
       tq[3 * lane + 0] = ry * fz - rz * fy; tq[3 * lane + 1] = rz * fx - rx * fz; tq[3 * lane + 2] = rx * fy - ry * fx;
@@ -671,7 +682,7 @@ template <int NV, int NW = 1> struct Solver {
     const bool live = irow < NZ;
     const int i = live ? irow : 0;              // idle lanes shadow row 0 and write only to the dump slot
     const int wlim = live ? i : 0;              // columns j < wlim are written
-    double *row = &L(D::oM + tri(i)), *dump = &L(D::oDUMP + lane);
+    double *row = &L(D::oM + tri(i)), *dump = &L(D::oDUMP + (lane & (D::DUMPN - 1)));
     const double m = L(D::oHDR + 20), muf = L(D::oHDR + 21);
     const double *x = &L(D::oXK);
     const double *sig = &L(D::oW0);
@@ -865,11 +876,27 @@ template <int NV, int NW = 1> struct Solver {
           double acc[10];
 #pragma unroll
           for (int q = 0; q < 10; ++q) acc[q] = 0.0;
+          const int tq0 = (rs == 2) ? tri(NXA - 10) : (rs == 1) ? tri(10) : 0;
+          int offq[10];
+#pragma unroll
+          for (int q = 0; q < 10; ++q) offq[q] = q * q0 + tri(q);
 #pragma unroll
           for (int n = 0; n < 6; ++n) {
             const double g = cg[n];
             double v[10];
-            lds_read_strided10<D::PS>(v, &L(D::oP + q0 * D::PS + cr[n]));
+            if constexpr (D::P_PACKED) {
+              // column c of the packed triangle, rows q0 .. q0 + 9: row <= c sits in row c of the triangle (contiguous),
+              // row >= c in its own row at column c.  The form is chosen on the address (one read per word): offq[q]
+              // = tri(q0 + q) - tri(q0) is per lane and shared by the six entries.
+              const int c = cr[n], t = c - q0;
+              const int ia = tri(c) + q0, ib = tq0 + c;
+              const double *pb[10];
+#pragma unroll
+              for (int q = 0; q < 10; ++q) pb[q] = &L(D::oP + ((q <= t) ? ia + q : ib + offq[q]));
+              lds_read_gather10(v, pb);
+            } else {
+              lds_read_strided10<D::PS>(v, &L(D::oP + q0 * D::PS + cr[n]));
+            }
 #pragma unroll
             for (int q = 0; q < 10; ++q) acc[q] += g * v[q];
           }
@@ -941,7 +968,7 @@ template <int NV, int NW = 1> struct Solver {
             }
             // masked-off columns are redirected to the lane's dump slot: per-element conditional
             // stores compile to a divergent branch with an exposed LDS round trip each
-            double *row = &L(D::oM + tri(rowi) + c0 + i0), *dump = &L(D::oDUMP + lane);
+            double *row = &L(D::oM + tri(rowi) + c0 + i0), *dump = &L(D::oDUMP + (lane & (D::DUMPN - 1)));
             double *pm[CT];
             double old[CT];
 #pragma unroll
@@ -991,7 +1018,7 @@ template <int NV, int NW = 1> struct Solver {
     // factorised: pivots and multipliers travel by readlane (the panel rows are lanes C0..C0+W-1 of the
     // first row set), so there is no LDS traffic and no barrier inside the block.
     double blk[NH][W];
-    double *dump = &L(D::oDUMP + lane);
+    double *dump = &L(D::oDUMP + (lane & (D::DUMPN - 1)));
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int rowi = lane + WS * h;
@@ -1154,8 +1181,12 @@ template <int NV, int NW = 1> struct Solver {
             const int i = 16 * rb + kq + 4 * r, j = 16 * cb + r16;
             const bool in = (i < NXA && j <= i && mine(rb, cb));
             const double v = old[rb][cb][r] - acc[rb][cb][r];
-            *(in ? &L(D::oP + i * D::PS + j) : dump) = v;
-            *(in ? &L(D::oP + j * D::PS + i) : dump) = v;
+            if constexpr (D::P_PACKED) {
+              *(in ? &L(D::oP + tri(i) + j) : dump) = v;
+            } else {
+              *(in ? &L(D::oP + i * D::PS + j) : dump) = v;
+              *(in ? &L(D::oP + j * D::PS + i) : dump) = v;
+            }
             *pm[rb][cb][r] = v;                 // and into the packed image the factor store copies out
           }
     } else {
@@ -1392,11 +1423,33 @@ template <int NV, int NW = 1> struct Solver {
       if (k < N) {
         // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG
         if (lane < NXA) {
-          const double *pr = &L(D::oP + lane * D::PS), *bv = &L(D::oBV);
+          const double *bv = &L(D::oBV);
           double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+          if constexpr (D::P_PACKED) {
+            // row `lane` of the packed triangle: columns <= lane contiguous in the row, the others down column `lane`
+            static_assert(!D::P_PACKED || NXA == 28, "two batches of fourteen");
+            double pr[NXA];
+            {
+              double va[14], vb[14];
+              lds_read_strided14<1>(va, &L(D::oP + tri(lane)));
+              lds_read_tri14_from0(vb, &L(D::oP + lane));
+#pragma unroll
+              for (int q = 0; q < 14; ++q) pr[q] = (q <= lane) ? va[q] : vb[q];
+              lds_read_strided14<1>(va, &L(D::oP + tri(lane) + 14));
+              lds_read_tri14_from14(vb, &L(D::oP + lane));
+#pragma unroll
+              for (int q = 0; q < 14; ++q) pr[14 + q] = (14 + q <= lane) ? va[q] : vb[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NXA; q += 4) {
+              b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
+            }
+          } else {
+          const double *pr = &L(D::oP + lane * D::PS);
 #pragma unroll
           for (int q = 0; q < NXA; q += 4) {
             b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
+          }
           }
           const double a = (b0 + b1) + (b2 + b3);
           L(D::oXN1 + lane) = L(D::oPC + lane) + a;       // v0 = p0_{k+1} + P_{k+1} b
@@ -1421,7 +1474,8 @@ template <int NV, int NW = 1> struct Solver {
         for (int e = lane; e < NXA * NXA; e += WS) {
           const int i = e / NXA, c = e % NXA;
           const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
-          L(D::oP + i * D::PS + c) = L(D::oM + tri(NU + hi) + NU + lo);
+          if constexpr (D::P_PACKED) { if (c <= i) L(D::oP + tri(i) + c) = L(D::oM + tri(NU + i) + NU + c); }
+          else L(D::oP + i * D::PS + c) = L(D::oM + tri(NU + hi) + NU + lo);
         }
         sync();
       }
