@@ -890,9 +890,9 @@ template <int NV, int NW = 1> struct Solver {
               // = tri(q0 + q) - tri(q0) is per lane and shared by the six entries.
               const int c = cr[n], t = c - q0;
               const int ia = tri(c) + q0, ib = tq0 + c;
-              const double *pb[10];
+              cmpc_lds_word pb[10];
 #pragma unroll
-              for (int q = 0; q < 10; ++q) pb[q] = &L(D::oP + ((q <= t) ? ia + q : ib + offq[q]));
+              for (int q = 0; q < 10; ++q) pb[q] = cmpc_lds_word_at(&L(D::oP), (q <= t) ? ia + q : ib + offq[q]);
               lds_read_gather10(v, pb);
             } else {
               lds_read_strided10<D::PS>(v, &L(D::oP + q0 * D::PS + cr[n]));
@@ -1427,18 +1427,23 @@ template <int NV, int NW = 1> struct Solver {
           double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
           if constexpr (D::P_PACKED) {
             // row `lane` of the packed triangle: columns <= lane contiguous in the row, the others down column `lane`
-            static_assert(!D::P_PACKED || NXA == 28, "two batches of fourteen");
-            double pr[NXA];
+            static_assert(!D::P_PACKED || NXA == 28, "three batches of ten");
+            double pr[30];
             {
-              double va[14], vb[14];
-              lds_read_strided14<1>(va, &L(D::oP + tri(lane)));
-              lds_read_tri14_from0(vb, &L(D::oP + lane));
+              const int tl = tri(lane);
 #pragma unroll
-              for (int q = 0; q < 14; ++q) pr[q] = (q <= lane) ? va[q] : vb[q];
-              lds_read_strided14<1>(va, &L(D::oP + tri(lane) + 14));
-              lds_read_tri14_from14(vb, &L(D::oP + lane));
+              for (int q0 = 0; q0 < 30; q0 += 10) {
+                cmpc_lds_word pa[10];
+                double v[10];
 #pragma unroll
-              for (int q = 0; q < 14; ++q) pr[14 + q] = (14 + q <= lane) ? va[q] : vb[q];
+                for (int q = 0; q < 10; ++q) {
+                  const int qq = (q0 + q < NXA) ? q0 + q : NXA - 1;          // (the last batch repeats column 27 twice)
+                  pa[q] = cmpc_lds_word_at(&L(D::oP), (qq <= lane) ? tl + qq : tri(qq) + lane);
+                }
+                lds_read_gather10(v, pa);
+#pragma unroll
+                for (int q = 0; q < 10; ++q) pr[q0 + q] = v[q];
+              }
             }
 #pragma unroll
             for (int q = 0; q < NXA; q += 4) {

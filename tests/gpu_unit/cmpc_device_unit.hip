@@ -32,11 +32,8 @@ __global__ void __launch_bounds__(64) k_lds_helpers(int *bad) {
   { double a[14], b[14]; cmpc::lds_read_pair14(a, b, base, base + 900);
     for (int i = 0; i < 14; ++i) nb += (a[i] != (3 * lane + 7 + i) + 0.25) + (b[i] != (3 * lane + 907 + i) + 0.25); }
   { double v[10]; cmpc::lds_read_strided10<29>(v, base); for (int i = 0; i < 10; ++i) nb += v[i] != (3 * lane + 7 + 29 * i) + 0.25; }
-  { double v[14]; cmpc::lds_read_tri14_from0(v, base); for (int i = 0; i < 14; ++i) nb += v[i] != (3 * lane + 7 + i * (i + 1) / 2) + 0.25; }
-  { double v[14]; cmpc::lds_read_tri14_from14(v, base);
-    for (int i = 0; i < 14; ++i) nb += v[i] != (3 * lane + 7 + (14 + i) * (15 + i) / 2) + 0.25; }
-  { double v[10]; const double *p[10];
-    for (int i = 0; i < 10; ++i) p[i] = lds + ((7 * lane + 131 * i * i + 5 * i) & 4095);       // ten unrelated addresses per lane
+  { double v[10]; cmpc::cmpc_lds_word p[10];
+    for (int i = 0; i < 10; ++i) p[i] = cmpc::cmpc_lds_word_at(lds, (7 * lane + 131 * i * i + 5 * i) & 4095);   // ten unrelated words per lane
     cmpc::lds_read_gather10(v, p);
     for (int i = 0; i < 10; ++i) nb += v[i] != ((7 * lane + 131 * i * i + 5 * i) & 4095) + 0.25; }
   { double v[56]; cmpc::lds_read_row<56>(v, base); for (int i = 0; i < 56; ++i) nb += v[i] != (3 * lane + 7 + i) + 0.25; }
