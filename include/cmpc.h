@@ -91,7 +91,7 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out);
 int cmpc_destroy(cmpc_handle *h);
 
 /* Device scratch of a handle for batches of up to B instances: the slabs (bounded by the resident grid of a 256-CU
- * part, allocated by cmpc_create) plus the queue-order array (4 bytes per instance; (re)allocated by the first
+ * part, allocated by cmpc_create) plus the queue-order arrays (8 bytes per instance; (re)allocated by the first
  * cmpc_solve_batch call with a larger B than any before -- that call synchronises the device and must not be made
  * under stream capture; later calls with B up to that size allocate nothing). */
 size_t cmpc_workspace_bytes(const cmpc_spec *spec, int32_t B);

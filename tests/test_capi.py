@@ -53,7 +53,7 @@ def test_workspace_bytes_and_argument_checks(lib):
     c = to_cspec(ProblemSpec(N=20, nv=4))
     small, big = lib.cmpc_workspace_bytes(ctypes.byref(c), 16), lib.cmpc_workspace_bytes(ctypes.byref(c), 1 << 20)
     assert 0 < small < big                                  # slabs are bounded by the resident grid, not by B;
-    assert lib.cmpc_workspace_bytes(ctypes.byref(c), 1 << 21) - big == 4 * (1 << 20)   # only the queue order (int32 per instance) grows
+    assert lib.cmpc_workspace_bytes(ctypes.byref(c), 1 << 21) - big == 8 * (1 << 20)   # only the queue order (position + bucket key per instance) grows
     bad = to_cspec(ProblemSpec(N=20, nv=4)); bad.nv = 5
     assert lib.cmpc_workspace_bytes(ctypes.byref(bad), 16) == 0
     h = ctypes.c_void_p()

@@ -40,7 +40,19 @@ def makespan(order):
 
 
 idx = np.arange(B)
-shipped = np.concatenate([idx[sw], idx[~sw][::-1]])
+switch_first = np.concatenate([idx[sw], idx[~sw][::-1]])          # the queue order of rounds 2-3 (switch class first)
+# the shipped order (csrc/cmpc_hip.hip, cmpc_order_bucket): decreasing predicted iteration count, 64 buckets of half an iteration
+chg = (np.diff(fl, axis=1) != 0).any(axis=2)
+first = np.where(sw, chg.argmax(axis=1), N).astype(float)
+gl0, gr0 = fl[:, 0, 0], fl[:, 0, 1]
+om = np.sqrt(spec.g / spec.cz_max)
+dcm = rec[:, 0:2] + rec[:, 3:5] / om
+both = (gl0 != 0) == (gr0 != 0)
+tgt = np.where(both[:, None], 0.5 * (rec[:, 13:15] + rec[:, 17:19]), np.where((gl0 != 0)[:, None], rec[:, 13:15], rec[:, 17:19]))
+d2 = ((dcm - tgt) ** 2).sum(axis=1)
+pred = 9.964 + 3.656 * sw + 0.158 * first + 1.916 * (gl0 + gr0) + 13.359 * np.sqrt(d2) + 170.148 * d2 + 0.075 * np.linalg.norm(rec[:, 6:9], axis=1)
+bucket = np.clip((2.0 * (pred - 10.0)).astype(int), 0, 63)
+shipped = np.argsort(-bucket, kind="stable")
 print(f"{name} B={B} N={N} nv={spec.nv}: kernel {ms:.1f} ms, slots {slots}, mean its {it.mean():.2f}, max {it.max()}, "
       f"switch class {sw.mean():.2%}")
 print("iterations: quantiles 50/90/99/100 =", [int(np.quantile(it, q)) for q in (0.5, 0.9, 0.99, 1.0)])
@@ -49,7 +61,9 @@ for cls, m in (("switch", sw), ("no switch", ~sw)):
         print(f"  {cls:10s} n={m.sum():5d} mean {it[m].mean():6.2f} q99 {int(np.quantile(it[m], 0.99))} max {it[m].max()}")
 bal = it.sum() / slots
 print(f"balanced bound {bal:.1f} instance-iterations per slot; longest instance {it.max()}")
-for lab, o in (("input order", idx), ("shipped (switch class first)", shipped), ("longest first (perfect knowledge)", np.argsort(-it))):
+print(f"predicted against measured iteration count: correlation {np.corrcoef(pred, it)[0, 1]:.2f}")
+for lab, o in (("input order", idx), ("switch class first (rounds 2-3)", switch_first), ("shipped (predicted count, 64 buckets)", shipped),
+               ("longest first (perfect knowledge)", np.argsort(-it))):
     mk = makespan(o)
     print(f"  {lab:36s} makespan {mk:5d} = {mk / bal:.3f} x balanced")
 print(f"time per instance-iteration at the shipped makespan: {ms / makespan(shipped) * 1e3:.1f} us")
