@@ -1,4 +1,5 @@
-"""Developer script: GPU vs C oracle on EVERY instance of the bench batch (8192 randomized, N = 20)."""
+"""Developer script: GPU vs C oracle on EVERY instance of a batch (default: the bench batch, 8192 randomized, N = 20).
+usage (GPU box): python tools/full_parity.py [workload] [B]   -- the workload's own horizon and vertex count"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +10,9 @@ from oracle import oracle_lib as ol
 
 name = sys.argv[1] if len(sys.argv) > 1 else "randomized"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-spec, rec = wl.make_workload(name, B=B, N=20)
+spec, rec = wl.make_workload(name, B=B)
+if spec.N > 20:
+    spec.max_iter = 150                                     # as bench.py and the parity tests run the long horizon
 out, st, it, kkt = BatchedCentroidalMPC(spec, device="cuda:0").solve(torch.from_numpy(rec).to("cuda:0"))
 torch.cuda.synchronize()
 got, st, it = out.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy()
