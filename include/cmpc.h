@@ -64,7 +64,8 @@ typedef struct cmpc_spec {
 /* Solver state carried from one closed-loop tick to the next (cmpc_solve_batch_state): the central-path point the
  * previous solve passed through at its last barrier value >= 1e-7 -- XU in the layout of out_XU, the dynamics
  * multipliers ((N+1) x (20 + 2 nv)), slacks and inequality multipliers ((N+1) x (15 + 10 nv) each), then the barrier
- * value (0 = no valid state), 7 spare words and the contact flags of the N+1 nodes (left, right).  Opaque to callers:
+ * value (0 = no valid state), 7 further words (the first: the iterations the solve that wrote the state took, by which the next launch queues the
+ * instance; 6 spare) and the contact flags of the N+1 nodes (left, right).  Opaque to callers:
  * pass last tick's state_out as state_in. */
 #define CMPC_NSTATE(N, nv) (CMPC_NSOL(N, nv) + ((N) + 1) * ((CMPC_NX + 2 * (nv)) + 2 * (15 + 10 * (nv)) + 2) + 8)
 

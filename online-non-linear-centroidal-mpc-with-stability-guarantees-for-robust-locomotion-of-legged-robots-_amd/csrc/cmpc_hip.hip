@@ -56,11 +56,21 @@ __device__ __forceinline__ int cmpc_order_bucket(const double *__restrict__ r, i
   return (b > 0.0) ? ((b < ORDER_BUCKETS - 1) ? (int)b : ORDER_BUCKETS - 1) : 0;   // (a NaN record lands in bucket 0)
 }
 
+// A resumed instance (valid solver state) is queued by what its previous solve took, which that solve left in the state's
+// first spare word: consecutive ticks of a closed loop take similar numbers of iterations.  One bucket per iteration
+// there; the formula's buckets (10 + b / 2 iterations) and these meet around 20 iterations, which is where a mixed
+// batch needs them comparable (an instance without a state is a cold solve).
 __global__ void __launch_bounds__(256) cmpc_order_score_kernel(int B, int N, double omega, const double *__restrict__ recs,
+                                                               const double *__restrict__ state_in, size_t nstate, size_t mu_word,
                                                                int *__restrict__ key, int *__restrict__ counters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
-  const int b = cmpc_order_bucket(recs + (size_t)i * CMPC_NREC(N), N, omega);
+  int b = -1;
+  if (state_in) {
+    const double ms = state_in[(size_t)i * nstate + mu_word], cnt = state_in[(size_t)i * nstate + mu_word + 1];
+    if (ms > 0.0 && ms < INFINITY && cnt >= 1.0 && cnt < 1e6) b = (cnt < ORDER_BUCKETS - 1) ? (int)cnt : ORDER_BUCKETS - 1;
+  }
+  if (b < 0) b = cmpc_order_bucket(recs + (size_t)i * CMPC_NREC(N), N, omega);
   key[i] = b;
   atomicAdd(counters + 3 + b, 1);
 }
@@ -335,7 +345,9 @@ int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, cons
   HIP_TRY(h, hipMemsetAsync(h->ticket, 0, ORDER_COUNTERS * sizeof(int), st));
   HIP_TRY(h, hipEventRecord(h->ev0, st));
   const double omega = sqrt(h->spec.g / h->spec.cz_max);                   // natural frequency of the pendulum at the height limit
-  hipLaunchKernelGGL(cmpc_order_score_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->spec.N, omega, params, h->order + B, h->ticket);
+  const size_t nstate = CMPC_NSTATE(h->spec.N, h->spec.nv), mu_word = nstate - 8 - 2 * (size_t)(h->spec.N + 1);
+  hipLaunchKernelGGL(cmpc_order_score_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->spec.N, omega, params, state_in, nstate,
+                     mu_word, h->order + B, h->ticket);
   hipLaunchKernelGGL(cmpc_order_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->order + B, h->order, h->ticket);
   if (h->spec.nv == 4)
     hipLaunchKernelGGL((cmpc_solve_kernel<4, 1>), dim3(grid), dim3(64), 0, st, ka, h->ticket, h->order);

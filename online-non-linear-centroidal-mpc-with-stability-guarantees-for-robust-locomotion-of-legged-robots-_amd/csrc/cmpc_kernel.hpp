@@ -1961,7 +1961,11 @@ template <int NV, int NW = 1> struct Solver {
     spent += it; resume = false;
     CMPC_SYNC_GLOBAL();
     }
-    if (lane == 0) { *status = st; *iters = it + spent; *kkt_out = kkt; }
+    if (lane == 0) {
+      *status = st; *iters = it + spent; *kkt_out = kkt;
+      // (first spare word of the state: what this solve took -- the next launch queues its instances by it)
+      if (state_out) GArr{state_out}[D::state_mu(N) + 1] = (double)(it + spent);
+    }
 #if defined(CMPC_PROFILE) && !defined(CMPC_HOST_EMU)
     if (lane == 0 && ka.prof)
       for (int i = 0; i < 28; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);

@@ -892,6 +892,8 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     solve_one(sp, rec, warm, out, st, verbose, full, NULL, state_out);
     st->iters += spent;
   }
+  /* first spare word of the state: what this solve took (the kernel's launch queues its instances by it) */
+  if (state_out) state_out[o_mu + 1] = (double)st->iters;
 }
 
 /* ------------------------------------ exported API -------------------------------------- */
