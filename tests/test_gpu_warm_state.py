@@ -47,6 +47,7 @@ def test_state_batch_matches_single_instances_and_plain_entry_point(oracle):
     a, st_a, it_a, _ = solver.solve(d)
     b, st_b, it_b, _ = solver.solve(d, state=s1, state_out=s2)               # empty state = the plain entry point
     assert torch.equal(a, b) and torch.equal(it_a, it_b)
+    assert torch.equal(s2[:, -7 - 2 * 11], it_b.double())                   # the state carries what the solve took (queue order of the next launch)
     # every instance again from its own state and solution: a handful of iterations, the same optimum
     c, st_c, it_c, _ = solver.solve(d, warm=b, state=s2, state_out=s1)
     w, st_w, it_w, _ = solver.solve(d, warm=b)                              # the same problem (proximal centre b) the plain way

@@ -72,6 +72,8 @@ def test_empty_state_is_the_plain_entry_point(oracle):
     ok = np.isin(st_b, (0, 3))
     mu = state[:, -8 - 2 * (10 + 1)]                                # barrier word (the contact flags of the N+1 nodes follow)
     assert ((mu[ok] >= 1e-7) & (mu[ok] <= 100.0)).all()            # a state was written for every solved instance
+    # the word after it: what the solve took (the launch of the next tick queues its instances by it)
+    assert np.array_equal(state[:, -7 - 2 * (10 + 1)], it_b.astype(np.float64))
 
 
 @pytest.fixture(scope="module")
