@@ -28,7 +28,11 @@ are counted as solves.  The same JSON line also carries
   wbc_qp        the batched whole-body inverse-dynamics QP at B = 65536
   roofline      HBM classification of SURVEY.md 8d: algorithmic bytes B_io per solve x solves per launch /
                 kernel time (HIP events on the launch stream, non-overlapped launch) vs 8 TB/s
-  cpu_baseline  the C oracle (a port, not CasADi/IPOPT) on all host cores, bounded sample, rank 0, N=1
+  cpu_baseline  the C oracle (a port, not CasADi/IPOPT) on the host cores this job really has (cgroup quota next to the
+                affinity mask), bounded sample, rank 0, N=1 -- plus SURVEY 8d's leg (a): one thread, one instance at a time
+  iterations / kkt quantiles of the timed batch (SURVEY 8d "Metric" row), per-rank step time and gather time at N > 1
+
+--seed S draws a fresh batch of the same distribution (default: the configuration's own seed).
 """
 import argparse
 import json
@@ -66,9 +70,85 @@ def measured_traffic(workload, batch, N):
     return best
 
 
-def self_launch(n, argv):
+CONFIG_OF = {"perturbed": 2, "payload": 3, "randomized": 4, "long_horizon": 5}     # BASELINE.json configs[i-1]
+
+
+def effective_cores():
+    """(cores this process can really use, details).  The affinity mask of a one-GPU lease lists every hardware thread of
+    the host (256) while the cgroup's CPU quota is what the job gets; a thread pool sized by the mask alone is
+    oversubscribed 16 times over.  cores = min(affinity, ceil(quota)) when a quota is set."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:                                                       # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    if quota is None:
+        try:                                                   # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(-(-quota // 1))))
+    return cores, {"sched_getaffinity": aff, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count()}
+
+
+def cpu_baseline(spec, rec_all, threads=None, budget_s=15.0, single_budget_s=6.0, solve_batch=None):
+    """The C oracle (oracle/cmpc_oracle.c: the same algorithm as the HIP kernel, -O3, OpenMP over the batch) timed on a
+    bounded sample of the bench batch: (b) all effective host cores, (a) one thread, one instance at a time.
+    The sample is a prefix of `rec_all`; every figure is computed from the number of instances the oracle returned a
+    status for -- never from the number asked for (rounds 2-3 divided 65 536 by the time of 8192 solves)."""
+    from oracle import oracle_lib as ol
+    solve_batch = solve_batch or ol.solve_batch
+    cores, detail = effective_cores()
+    threads = cores if threads is None else int(threads)
+    cs = ol.default_spec(N=spec.N, nv=spec.nv, tol=spec.tol, max_iter=spec.max_iter, k1=spec.k1, k2=spec.k2,
+                         prox=spec.prox, acc_tol=spec.acc_tol)
+    avail = rec_all.shape[0]
+    # calibrate on two instances per thread, then size the sample for ~budget_s of wall time
+    ncal = min(avail, max(8, 2 * threads))
+    t0 = time.perf_counter()
+    _, st_cal, _, _ = solve_batch(cs, rec_all[:ncal], nthreads=threads)
+    rate_cal = st_cal.shape[0] / max(time.perf_counter() - t0, 1e-6)
+    nsample = int(min(avail, max(ncal, rate_cal * budget_s)))
+    sample = rec_all[:nsample]
+    t0 = time.perf_counter()
+    _, st_c, it_c, _ = solve_batch(cs, sample, nthreads=threads)
+    dt = time.perf_counter() - t0
+    solved = int(st_c.shape[0])
+    assert solved == sample.shape[0]
+    conv = float((st_c == 0).mean())
+    # leg (a): the reference's own use -- one instance per call, one thread (code/simulation.py:203-204)
+    n1, t1 = 0, time.perf_counter()
+    st1 = []
+    while n1 < min(avail, 256) and (n1 < 64 or time.perf_counter() - t1 < single_budget_s):
+        _, s_, _, _ = solve_batch(cs, rec_all[n1:n1 + 1], nthreads=1)
+        st1.append(int(s_[0]))
+        n1 += 1
+    dt1 = time.perf_counter() - t1
+    conv1 = float(np.mean(np.asarray(st1) == 0))
+    return {"value": solved / dt * conv, "unit": "solves/s", "cores": threads, "kind": "port",
+            "all_instances_per_s": solved / dt, "instances_solved": solved, "seconds": dt, "converged": conv,
+            "mean_iterations": float(it_c.mean()),
+            "single_thread_solves_per_s": n1 / dt1 * conv1, "single_thread_all_instances_per_s": n1 / dt1,
+            "single_thread_instances_solved": n1, "single_thread_ms_per_instance": dt1 / n1 * 1e3,
+            "host": detail,
+            "sample": f"first {solved} instances of the timed batch, C oracle (same algorithm, -O3, OpenMP over the batch), "
+                      f"{threads} threads = min(affinity mask {detail['sched_getaffinity']}, cgroup CPU quota "
+                      f"{detail['cgroup_cpu_quota']}), {dt:.1f} s, converged-only like `value`; single-thread leg: {n1} "
+                      f"instances one at a time, {dt1:.1f} s; CasADi/IPOPT cannot run here (SURVEY 8c)"}
+
+
+def self_launch(n, argv, timeout_s=None):
     """Start the n ranks of `bench.py --gpus n` as child processes (one per GPU, rendezvous on 127.0.0.1) and
-    return the worst exit code.  Runs in a parent that has not imported torch and never touches the GPU."""
+    return the worst exit code.  Runs in a parent that has not imported torch and never touches the GPU.  The parent
+    ends its own children (the exact PIDs it started) when one of them fails, when `timeout_s` passes (a rank hung in a
+    collective), and when it is itself told to stop (SIGTERM / SIGINT)."""
+    import signal
     import socket
     import subprocess
     s = socket.socket()
@@ -76,6 +156,12 @@ def self_launch(n, argv):
     port = s.getsockname()[1]
     s.close()
     procs = []
+
+    def stop_children(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    old_handlers = {sig: signal.signal(sig, lambda *_: (stop_children(), sys.exit(128 + 15))) for sig in (signal.SIGTERM, signal.SIGINT)}
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CMPC_BENCH_CHILD="1")
@@ -83,6 +169,7 @@ def self_launch(n, argv):
         env.setdefault("OMP_NUM_THREADS", "4")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     worst = 0
+    t_start = time.monotonic()
     try:
         pending = set(range(n))
         while pending:
@@ -96,11 +183,22 @@ def self_launch(n, argv):
                     print(f"bench.py: rank {r} exited with code {rc}; stopping the other ranks", file=sys.stderr)
                     for q in pending:                       # the exact PIDs this parent started, nothing else
                         procs[q].terminate()
+            if pending and timeout_s and time.monotonic() - t_start > timeout_s:
+                print(f"bench.py: ranks {sorted(pending)} still running after --launch-timeout {timeout_s:.0f} s; "
+                      f"stopping them", file=sys.stderr)
+                stop_children()
+                worst = worst or 124
+                break
             time.sleep(0.05)
     finally:
+        deadline = time.monotonic() + 10.0
         for p in procs:
+            while p.poll() is None and time.monotonic() < deadline:
+                time.sleep(0.05)
             if p.poll() is None:
                 p.kill()
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
     return worst
 
 
@@ -113,6 +211,10 @@ def main():
                     help="HIP streams (solver handles) the timed steps alternate over; 1 = strictly serial (headline)")
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU")
     ap.add_argument("--workload", default="randomized", choices=sorted(PER_GPU_BATCH))
+    ap.add_argument("--seed", type=int, default=None,
+                    help="seed of the synthetic batch (default: the configuration's own, SURVEY 8d)")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="bare --gpus N launcher: seconds after which ranks still running are stopped (exit code 124)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the pipelined / warm-start / batch-sweep legs")
     args = ap.parse_args()
@@ -121,7 +223,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started bare: be the launcher (no torch import, no HIP call, no exec in this process)
-        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], timeout_s=args.launch_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -133,19 +235,24 @@ def main():
 
     if os.environ.get("CMPC_BENCH_DRYRUN") == "1":
         # launcher rehearsal for the CPU tier (tests/test_bench_launch.py): rendezvous over gloo, one gather through the
-        # product's dist layer, rank 0 prints a line -- no solver, no GPU.  CMPC_BENCH_DRYRUN_FAIL=r makes rank r fail.
+        # product's dist layer, rank 0 prints a line -- no solver, no GPU.  CMPC_BENCH_DRYRUN_FAIL=r makes rank r fail,
+        # CMPC_BENCH_DRYRUN_HANG=r makes rank r hang (the launcher's timeout must end it).
         import cmpc_amd  # noqa: F401
         from cmpc_amd import dist as cdist
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         if os.environ.get("CMPC_BENCH_DRYRUN_FAIL") == str(rank):
             raise SystemExit(3)
+        if os.environ.get("CMPC_BENCH_DRYRUN_HANG") == str(rank):
+            time.sleep(600)
         lo, hi = cdist.shard_bounds(10 * world + 3, world, rank)
         full = cdist.gather_shards(torch.arange(lo, hi, dtype=torch.float64)[:, None], 10 * world + 3)
         ok = bool((full[:, 0] == torch.arange(10 * world + 3, dtype=torch.float64)).all())
+        stats = cdist.gather_rank_stats([float(rank), 2.0 * rank])
         if rank == 0:
             print(json.dumps({"dryrun": True, "n_gpus": world, "gathered_in_order": ok,
-                              "n_ranks_seen": dist.get_world_size() if world > 1 else 1}))
+                              "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+                              "rank_stats": stats.tolist()}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -170,7 +277,7 @@ def main():
     from cmpc_amd.solver import BatchedCentroidalMPC
 
     B_total = args.batch * world
-    spec, rec_all = wl.make_workload(args.workload, B=B_total)
+    spec, rec_all = wl.make_workload(args.workload, B=B_total, seed=args.seed)
     if spec.N > 20:
         spec.max_iter = 150                                        # long horizons take more iterations
     lo, hi = cdist.shard_bounds(B_total, world, rank)
@@ -180,14 +287,26 @@ def main():
     streams = [torch.cuda.Stream(device=device) for _ in range(n_handles)]
     outs = [torch.empty((hi - lo, spec.nsol), dtype=torch.float64, device=device) for _ in range(n_handles)]
 
-    def step(i, S, records=rec, warm=None, state=None, state_out=None):
+    def step(i, S, records=rec, warm=None, state=None, state_out=None, marks=None):
         j = i % S
         with torch.cuda.stream(streams[j]):
+            # HIP events on the launch stream around the solve call (memset + two queue-order kernels + the solve kernel)
+            # and around the collective, for every timed step
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if marks is not None else None
+            if ev:
+                ev[0].record()
             XU, status, iters, kkt = solvers[j].solve(records, warm=warm, out=outs[j][:records.shape[0]],
                                                       state=state, state_out=state_out)
+            if ev:
+                ev[1].record()
             fb = cdist.first_stage_feedback(XU, spec.N, spec.nu)
-            packed = torch.cat((fb, status.to(fb.dtype)[:, None], iters.to(fb.dtype)[:, None]), dim=1)
+            packed = torch.cat((fb, kkt[:, None], status.to(fb.dtype)[:, None], iters.to(fb.dtype)[:, None]), dim=1)
+            if ev:
+                ev[2].record()
             full = cdist.gather_shards(packed, B_total) if records is rec else packed   # the ONE collective
+            if ev:
+                ev[3].record()
+                marks.append(ev)
         return full
 
     def sync():
@@ -196,27 +315,33 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    def timed(S, steps, warmup, **kw):
+    def timed(S, steps, warmup, marks=None, **kw):
         for i in range(warmup):
             step(i, S, **kw)
         sync()
         t0 = time.perf_counter()
         for i in range(steps):
-            full = step(i, S, **kw)
+            full = step(i, S, marks=marks, **kw)
+        torch.cuda.synchronize(device)
+        el_local = time.perf_counter() - t0                          # this rank's own steps, before it waits for the others
         sync()
         el = time.perf_counter() - t0
         t_max = torch.tensor([el], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        return float(t_max.item()), full
+        return float(t_max.item()), full, el_local
 
     S = max(1, args.streams)
-    elapsed, full = timed(S, args.steps, args.warmup)
-    # HIP events around the last launch of handle 0, on its own launch stream
-    kernel_ms = float(np.mean([solvers[j].last_kernel_ms() for j in range(min(S, args.steps))]))
+    marks = []
+    elapsed, full, el_local = timed(S, args.steps, args.warmup, marks=marks)
+    # kernel time: AVERAGE over the timed launches (round 3 read the last launch only: 115 - 121 ms spread)
+    k_ms = [m[0].elapsed_time(m[1]) for m in marks]
+    g_ms = [m[2].elapsed_time(m[3]) for m in marks]
+    kernel_ms = float(np.mean(k_ms))
 
     st = full[:, -2].to(torch.int32)
     it = full[:, -1]
+    kk = full[:, -3]
     frac = {name: float((st == code).double().mean().item())
             for name, code in (("converged", 0), ("iteration_cap", 1), ("status_2", 2), ("acceptable", 3))}
     mean_iters = float(it.mean().item())
@@ -229,6 +354,18 @@ def main():
     per_step = 1.2 * spec.N * (7.0 / 3.0 * 20 ** 3 + 4.0 * 20 ** 2 * spec.nu + 2.0 * 20 * spec.nu ** 2 + spec.nu ** 3 / 3.0)
     flops = per_step * mean_iters * (hi - lo) / (kernel_ms * 1e-3) / 1e12
 
+    def quantiles(t, qs):
+        t = t.double().flatten()
+        if t.numel() == 0:
+            return {f"q{int(q * 100)}": None for q in qs}
+        v = torch.quantile(t, torch.tensor(qs, dtype=torch.float64, device=t.device))
+        return {f"q{int(q * 100)}": float(x) for q, x in zip(qs, v.tolist())}
+    use = (st == 0) | (st == 3)
+    it_q = dict(quantiles(it, [0.5, 0.9, 0.99]), max=float(it.max().item()), mean=mean_iters)
+    kkt_q = dict(quantiles(kk[use], [0.5, 0.9, 0.99]), max=float(kk[use].max().item()) if bool(use.any()) else None,
+                 note="final scaled KKT error of the usable instances (status 0 or 3)")
+
+    nw = 2 if spec.nv == 8 else 1
     traffic = measured_traffic(args.workload, args.batch, spec.N)
     result = {
         "metric": f"centroidal-MPC solves/sec, N={spec.N} horizon",
@@ -236,13 +373,15 @@ def main():
         "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BASELINE config {5 if args.workload == 'long_horizon' else 4} shard: {args.workload}, "
-                               f"batch {args.batch}/GPU ({B_total} total), N={spec.N}, 2 feet x {spec.nv} vertices, cold start",
+        "config": {"workload": f"BASELINE config {CONFIG_OF[args.workload]}{' shard' if CONFIG_OF[args.workload] >= 4 else ''}: "
+                               f"{args.workload}, batch {args.batch}/GPU ({B_total} total), N={spec.N}, 2 feet x {spec.nv} "
+                               f"vertices, cold start",
                    "global_batch": B_total, "horizon": spec.N, "tol": spec.tol, "acc_tol": spec.acc_tol,
-                   "max_iter": spec.max_iter, "mean_iterations": mean_iters,
+                   "max_iter": spec.max_iter, "mean_iterations": mean_iters, "seed": args.seed if args.seed is not None else wl.CONFIGS[args.workload][0],
                    "counted_as_solves": "status 0 only (scaled KKT error <= tol)",
-                   "parallelism": f"batch-sharded x{world}, final all-gather of (x1,u0,status); "
+                   "parallelism": f"batch-sharded x{world}, final all-gather of (x1,u0,kkt,status,iters); "
                                   f"{'strictly serial launches' if S == 1 else f'steps alternate over {S} HIP streams'}"},
+        "iterations": it_q, "kkt": kkt_q,
         "outcome": dict(frac, usable_solves_per_s=rate_all * (frac["converged"] + frac["acceptable"]),
                         all_instances_per_s=rate_all,
                         note="status_2 = no usable point (include/cmpc.h: step length collapsed, regularisation exhausted "
@@ -252,15 +391,29 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                      "traffic_source": traffic[1] if traffic else None,
-                     "kernel": f"cmpc_solve_kernel<{spec.nv}>", "kernel_ms": kernel_ms, "concurrent_launches": S,
+                     "kernel": f"cmpc_solve_kernel<{spec.nv}, {nw}>", "kernel_ms": kernel_ms,
+                     "kernel_ms_min": float(np.min(k_ms)), "kernel_ms_max": float(np.max(k_ms)), "kernel_launches_timed": len(k_ms),
+                     "kernel_ms_note": "average over the timed launches, HIP events on the launch stream around each solve "
+                                       "call (memset, two queue-order kernels, the solve kernel)",
+                     "concurrent_launches": S,
                      "algorithmic_bytes_per_solve": b_io,
                      "note": "latency/FP64-issue bound in practice (SURVEY 8d): see fp64_tflops",
                      "fp64_tflops_model": flops, "fp64_frac_of_vector_peak": flops / FP64_VECTOR_PEAK_TFLOPS},
     }
+    if world > 1:
+        # per-rank view of the timed region: a slow rank (skew) and a slow collective look different here
+        stats = cdist.gather_rank_stats([el_local / args.steps * 1e3, float(np.mean(k_ms)), float(np.mean(g_ms)), float(np.max(g_ms))])
+        result["ranks"] = {"ms_per_step_local": {"min": float(stats[:, 0].min()), "max": float(stats[:, 0].max()),
+                                                 "per_rank": [float(x) for x in stats[:, 0]]},
+                           "kernel_ms": {"min": float(stats[:, 1].min()), "max": float(stats[:, 1].max())},
+                           "gather_ms": {"mean_min": float(stats[:, 2].min()), "mean_max": float(stats[:, 2].max()),
+                                         "worst": float(stats[:, 3].max())},
+                           "note": "ms_per_step_local = a rank's own steps before it waits for the others; gather_ms = HIP "
+                                   "events around the all-gather on the launch stream (includes waiting for the slowest rank)"}
 
     if world == 1 and not args.no_extras:
         # --- independent batches pipelined over two streams
-        el2, full2 = timed(2, args.steps, 2)
+        el2, full2, _ = timed(2, args.steps, 2)
         c2 = float((full2[:, -2] == 0).double().mean().item())
         result["pipelined"] = {"streams": 2, "converged_solves_per_s": B_total * args.steps / el2 * c2,
                                "all_instances_per_s": B_total * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3,
@@ -271,7 +424,7 @@ def main():
         state0, state1 = solvers[0].new_state(rec.shape[0]), solvers[0].new_state(rec.shape[0])
         cold = solvers[0].solve(rec, state_out=state0)[0].clone()
         sync()
-        elw, fullw = timed(1, max(2, args.steps // 2), 1, warm=cold, state=state0, state_out=state1)
+        elw, fullw, _ = timed(1, max(2, args.steps // 2), 1, warm=cold, state=state0, state_out=state1)
         cw = float((fullw[:, -2] == 0).double().mean().item())
         result["warm_start"] = {"converged_solves_per_s": B_total * max(2, args.steps // 2) / elw * cw,
                                 "all_instances_per_s": B_total * max(2, args.steps // 2) / elw,
@@ -282,12 +435,12 @@ def main():
         # --- batch-size sweep of the metric (one launch per size, fresh synthetic batch of that size)
         sweep = {}
         for Bs in (1, 16, 256, 4096, 65536):
-            _, rs = wl.make_workload(args.workload, B=Bs, N=spec.N)
+            _, rs = wl.make_workload(args.workload, B=Bs, N=spec.N, seed=args.seed)
             d = torch.from_numpy(rs).to(device)
             if Bs > outs[0].shape[0]:
                 outs[0] = torch.empty((Bs, spec.nsol), dtype=torch.float64, device=device)
             reps = 3
-            els, fs = timed(1, reps, 1, records=d)
+            els, fs, _ = timed(1, reps, 1, records=d)
             cs_ = float((fs[:, -2] == 0).double().mean().item())
             sweep[str(Bs)] = {"ms_per_launch": els / reps * 1e3, "all_instances_per_s": Bs * reps / els,
                               "converged_solves_per_s": Bs * reps / els * cs_}
@@ -297,10 +450,9 @@ def main():
     if world == 1 and not args.no_extras:
         # --- the next row of the scope table: batched whole-body inverse-dynamics QP, B = 65536
         from cmpc_amd import wbc
-        from oracle import wbc_qp_oracle as wq        # synthetic matrices only here; the oracle's solver is timed below
         Bq, uniq = 65536, 1024
         mats = [torch.from_numpy(np.ascontiguousarray(np.tile(a, (Bq // uniq,) + (1,) * (a.ndim - 1)))).to(device)
-                for a in wq.synthetic(uniq, seed=20250715)]
+                for a in wl.wbc_synthetic(uniq, seed=20250715)]
         qp = wbc.BatchedInverseDynamicsQP(foot_size=0.1, mu=0.5, device=device)
         qp.solve(*mats)
         torch.cuda.synchronize(device)
@@ -321,9 +473,10 @@ def main():
                                     "30 dofs, double support), wbc_qp_kernel, KKT error <= 1e-9; latency bound like the MPC "
                                     "kernel (one wave per QP, 48 serial pivots per Newton step)"}
         if not args.no_cpu_baseline:
+            from oracle import wbc_qp_oracle as wq        # the numpy oracle of the QP, timed on one core
             t0 = time.perf_counter()
             nq = 0
-            Hs, Fs, Ms, hs, Js = wq.synthetic(64, seed=20250715)
+            Hs, Fs, Ms, hs, Js = wl.wbc_synthetic(64, seed=20250715)
             while time.perf_counter() - t0 < 5.0 and nq < 64:
                 wq.solve(Hs[nq], Fs[nq], Ms[nq], hs[nq], Js[nq], 0.05, 0.5)
                 nq += 1
@@ -331,23 +484,7 @@ def main():
         del mats
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle_lib as ol
-        # all host cores this process may run on (the GPU box hands a one-GPU job a share of the host's cores)
-        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        nsample = max(64, (256 if spec.N <= 20 else 2) * threads)
-        sample = rec_all[:nsample]
-        cs = ol.default_spec(N=spec.N, nv=spec.nv, tol=spec.tol, max_iter=spec.max_iter, k1=spec.k1, k2=spec.k2,
-                             prox=spec.prox, acc_tol=spec.acc_tol)
-        ol.solve_batch(cs, sample[:threads], nthreads=threads)      # warm the library
-        t0 = time.perf_counter()
-        _, st_c, it_c, _ = ol.solve_batch(cs, sample, nthreads=threads)
-        dt = time.perf_counter() - t0
-        result["cpu_baseline"] = {"value": nsample / dt * float((st_c == 0).mean()), "unit": "solves/s", "cores": threads,
-                                  "kind": "port", "all_instances_per_s": nsample / dt,
-                                  "sample": f"first {nsample} instances of the same workload, C oracle "
-                                            f"(same algorithm, -O3, OpenMP over the batch, {threads} threads = every core this "
-                                            f"process may use, os.cpu_count() = {os.cpu_count()}), {dt:.1f} s, converged-only like `value`; "
-                                            f"CasADi/IPOPT cannot run here (SURVEY 8c)"}
+        result["cpu_baseline"] = cpu_baseline(spec, rec_all)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

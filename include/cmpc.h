@@ -33,7 +33,8 @@ extern "C" {
 typedef struct cmpc_spec {
   int32_t N;                  /* horizon, params['N'] (:10)                           */
   int32_t nv;                 /* contact vertices per foot: 4 (reference, :55-60) or 8 */
-  int32_t max_iter;           /* interior-point iteration cap                         */
+  int32_t max_iter;           /* interior-point iteration cap: iters[] <= max_iter + 1, also for a resumed solve that
+                                 falls back to the plain one (the two attempts share the budget)          */
   int32_t struct_size;        /* sizeof(cmpc_spec): set by cmpc_default_spec, checked by cmpc_create (a caller built
                                  against an older, shorter layout is refused instead of read past its end)      */
   double delta;               /* world_time_step*mpc_rate (:11)                       */
@@ -113,14 +114,16 @@ int cmpc_solve_batch(cmpc_handle *h, int32_t B, const double *params, const doub
  * Closed-loop form of cmpc_solve_batch: the solver state of the previous tick comes in, this tick's goes out.
  *   state_in   [B][CMPC_NSTATE(N,nv)]  last tick's state_out; NULL (or a state whose barrier word is 0) = start as
  *                                      cmpc_solve_batch does
- *   state_out  [B][CMPC_NSTATE(N,nv)]  may be NULL; may NOT alias state_in
+ *   state_out  [B][CMPC_NSTATE(N,nv)]  may be NULL; may NOT overlap state_in (checked: the call fails)
  * The state is the interior point method's own iterate at its last barrier value >= 1e-7 -- a point on the central
  * path of this tick's problem, one level short of the solution -- and the next solve resumes from it at that barrier
  * value instead of restarting at mu = 100 from the boundary solution (10.0 instead of 17.7 iterations per tick on
  * the flat-ground walk).  warm_XU keeps its
  * meaning (previous solution: proximal centre; initial guess only when there is no valid state).  Replaces the
  * reference's opt.set_initial(sol.value(...)) (code/centroidal_mpc_vertices.py:630-631), which IPOPT likewise uses
- * for the primal variables only.
+ * for the primal variables only.  A resumed solve whose state does not fit this tick's problem (still at the state's
+ * barrier value after 20 iterations, or ending without a usable point) is followed by the plain solve inside the same
+ * call with what is left of max_iter; iters[] reports both attempts.
  */
 int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, const double *warm_XU,
                            const double *state_in, double *out_XU, double *state_out, int32_t *status,

@@ -15,7 +15,8 @@
  *   M  [B][30][30]  h  [B][30]   mass matrix, Coriolis + gravity forces
  *   Jc [B][12][30]               contact Jacobian, rows already scaled by the contact flags (:109)
  * Outputs: tau [B][30] (tau[0:6] = 0: the statement leaves them free and the reference discards them), qdd [B][30],
- * f_c [B][12], status [B] (0 = KKT error <= tol, 1 = iteration cap, 2 = numerical failure), iters [B].
+ * f_c [B][12], status [B] (0 = KKT error <= tol, 1 = iteration cap, 2 = numerical failure; for 1 and 2 tau, qdd and f_c are
+ * ZEROS, the reference's QPSolver.solve on failure, code/utils.py:85-92), iters [B].
  * Asynchronous on `stream` (hipStream_t; NULL = default stream).  Returns 0 on success; message via cmpc_wbc_last_error.
  */
 #ifndef CMPC_WBC_H

@@ -326,6 +326,13 @@ int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, cons
   if (B < 0) return fail(h, "cmpc_solve_batch: negative batch");
   if (B == 0) return 0;
   if (!params || !out_XU || !status || !iters || !kkt_res) return fail(h, "cmpc_solve_batch: null buffer");
+  if (state_in && state_out) {
+    // the kernel invalidates state_out's barrier word before it reads state_in's, and the order kernel reads state_in
+    // in the same launch: overlapping ranges would resume from a half-overwritten state without any error
+    const size_t bytes = (size_t)B * CMPC_NSTATE(h->spec.N, h->spec.nv) * sizeof(double);
+    const uintptr_t a = (uintptr_t)state_in, b = (uintptr_t)state_out;
+    if (a < b + bytes && b < a + bytes) return fail(h, "cmpc_solve_batch_state: state_in and state_out overlap");
+  }
   hipStream_t st = (hipStream_t)stream;
   DeviceGuard guard(h->device);
   if (!guard.ok) return fail(h, "cmpc_solve_batch: cannot select the handle's device");
@@ -442,7 +449,7 @@ int cmpc_build_records_planned(const cmpc_tables *tb, int32_t N, int32_t rate, i
 }
 
 const char *cmpc_last_error(cmpc_handle *h) { return h ? h->err.c_str() : g_err.c_str(); }
-const char *cmpc_version(void) { return "cmpc_amd 0.1 (gfx950)"; }
+const char *cmpc_version(void) { return "cmpc_amd 0.4 (gfx950)"; }
 
 #ifdef CMPC_PROFILE
 /* diagnostic build only: read and reset the phase cycle sums */

@@ -119,6 +119,9 @@ constexpr double MU_FACTOR = 0.1;
 // warm start of the interior point method: the solver state is the iterate at the last barrier value >= MU_WARM
 // (see the oracle for the choice of the level)
 constexpr double MU_WARM = 1e-7;
+// a resumed solve that has not left the state's barrier value after this many iterations gives up (the state was too far
+// from this tick's problem) and the plain solve follows, with what is left of the iteration budget (see the oracle)
+constexpr int RESUME_RECENTRE_ITERS = 20;
 // waves per instance of the 8-vertex solver (Solver<8, WAVES_NV8>; the 4-vertex one is a single wave)
 constexpr int WAVES_NV8 = 2;
 
@@ -1863,9 +1866,10 @@ template <int NV, int NW = 1> struct Solver {
       if (resume) st_in = GArr{const_cast<double *>(state_in)};
     }
     int st = CMPC_MAX_ITER, it = 0, spent = 0;
+    int cap = sp.max_iter;                      // iteration budget of the attempt: both attempts together stay within max_iter
     double kkt = INFINITY;
     // at most two attempts: a resumed solve that gets nowhere (the state was too far from this tick's problem) is
-    // followed by the plain one; the iterations of both are reported (see the oracle)
+    // followed by the plain one with the rest of the budget; the iterations of both are reported (see the oracle)
     for (;;) {
     if (state_out && lane == 0) GArr{state_out}[D::state_mu(N)] = 0.0;     // invalid until a snapshot is taken
     double mu = resume ? st_in[D::state_mu(N)] : MU_INIT;
@@ -1887,7 +1891,7 @@ template <int NV, int NW = 1> struct Solver {
     auto save_tol = [&]() { return fmax(fmax(sp.acc_tol, tol), ACC_FACTOR * tol); };
     initial_point(resume ? state_in : warm, warm, resume);
     CMPC_TICK_RESET();
-    for (it = 0; it <= sp.max_iter; ++it) {
+    for (it = 0; it <= cap; ++it) {
       double reg = 0.0;
       Err er;
       bool fail = false;
@@ -1934,10 +1938,12 @@ template <int NV, int NW = 1> struct Solver {
         }
       }
       if (polish == 0) { st = CMPC_CONVERGED; break; }
-      if (it == sp.max_iter || !(kkt < INFINITY) || n_stall >= STALL_ITERS) {
+      // a resumed solve still at the state's barrier value: the state does not fit this tick's problem
+      const bool stale = resume && it >= RESUME_RECENTRE_ITERS && polish < 0 && mu == st_in[D::state_mu(N)];
+      if (it == cap || !(kkt < INFINITY) || n_stall >= STALL_ITERS || stale) {
         if (polish >= 0) st = CMPC_CONVERGED;                   // (cap reached inside the polish)
-        else if (ks <= acc_tol()) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; }
-        else st = (it == sp.max_iter) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
+        else if (ks <= acc_tol() && !stale) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; }
+        else st = (it == cap && !stale) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
         break;
       }
       if (reg > 0) reg_last = reg;
@@ -1958,7 +1964,8 @@ template <int NV, int NW = 1> struct Solver {
     }
     if (!use_saved) write_solution(out);
     if (!(resume && (st == CMPC_MAX_ITER || st == CMPC_NUMERICAL))) break;
-    spent += it; resume = false;
+    if (it >= sp.max_iter) break;               // nothing left of the budget
+    spent += it; cap = sp.max_iter - it; resume = false;
     CMPC_SYNC_GLOBAL();
     }
     if (lane == 0) {

@@ -8,10 +8,12 @@
 //   * primal-dual interior point on the 42-variable problem, the same monotone barrier schedule and
 //     fraction-to-the-boundary rule as the centroidal MPC solver;
 //   * every Newton step is one L D L' factorisation of the 48 x 48 quasi-definite KKT matrix
-//         [ Hq                                 M_b'  ]      lane i owns row i of the lower triangle IN REGISTERS
-//         [      1e-6 I + A' diag(z/s) A      -Jc_b  ]      (48 doubles); column j travels to the other lanes through a
-//         [ M_b        -Jc_b'                   0    ]      48-word LDS buffer (one write, one batch of uniform reads)
-//     followed by two triangular solves against the factor written out to LDS.
+//         [ Hq                                 M_b'  ]      in LDS, lane i owns row i of the lower triangle (row stride
+//         [      1e-6 I + A' diag(z/s) A      -Jc_b  ]      49: column reads across lanes are conflict free); column j
+//         [ M_b        -Jc_b'                   0    ]      is read by every lane at wave-uniform addresses
+//     followed by two triangular solves against the factor (v_readlane broadcasts of the running solution).
+// Failure (status 1 / 2: iteration cap, wrong-inertia pivot, non-finite KKT error) returns zeros in tau, qdd and f_c, as
+// the reference's QPSolver.solve does when OSQP fails (code/utils.py:85-92).
 // The problem data of an instance (Hq, M_b, Jc_b: 8.4 KB) is staged in LDS once; per iteration nothing touches HBM.
 // Instances are independent: workgroups stride over the batch, no inter-workgroup communication.
 #include <hip/hip_runtime.h>
@@ -41,8 +43,7 @@ constexpr int oS = oNU + NB;                             // s (16)
 constexpr int oZ = oS + NI;                              // z (16)
 constexpr int oSIG = oZ + NI;                            // z / s (16)
 constexpr int oW = oSIG + NI;                            // mu / s + sigma * (A x + s) (16)
-constexpr int oCOL = oW + NI;                            // column buffer of the factorisation (48)
-constexpr int oRHS = oCOL + NK;                          // right-hand side / solution (48)
+constexpr int oRHS = oW + NI;                            // right-hand side / solution (48)
 constexpr int LS = NK + 1;
 constexpr int oL = oRHS + NK;                            // L (48 x 49), D on the diagonal
 constexpr int oK0 = oL + NK * LS;                        // constant part of the KKT matrix, lower triangle (48 x 49)
@@ -246,11 +247,13 @@ __global__ void __launch_bounds__(64) wbc_qp_kernel(int B, const double *__restr
       lds_fence();
     }
     // ---- outputs: qdd, f_c, tau[6:] = M_a qdd + h_a - Jc_a' f_c  (tau[0:6] = 0)
-    if (lane < ND) qdd[(size_t)b * ND + lane] = L[oX + lane];
-    if (lane < NC) fc[(size_t)b * NC + lane] = L[oX + ND + lane];
+    // (failure: zeros, the reference's behaviour -- never the last iterate, which may be NaN / Inf after a bad pivot)
+    const bool good = st == 0;
+    if (lane < ND) qdd[(size_t)b * ND + lane] = good ? L[oX + lane] : 0.0;
+    if (lane < NC) fc[(size_t)b * NC + lane] = good ? L[oX + ND + lane] : 0.0;
     if (lane < ND) {
       double t = 0.0;
-      if (lane >= NB) {
+      if (lane >= NB && good) {
         t = hvec[(size_t)b * ND + lane];
         for (int j = 0; j < ND; ++j) t += Mb[lane * ND + j] * L[oX + j];
         for (int c = 0; c < NC; ++c) t -= Jb[c * ND + lane] * L[oX + ND + c];
@@ -278,9 +281,14 @@ int cmpc_wbc_qp_solve_batch(int device, int32_t B, const double *Hq, const doubl
   int prev = -1;
   if (hipGetDevice(&prev) != hipSuccess) prev = -1;
   if (prev != device && hipSetDevice(device) != hipSuccess) { g_wbc_err = "cmpc_wbc_qp_solve_batch: bad device"; return 1; }
-  hipDeviceProp_t prop;
-  int cus = 256;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+  // CU count per device, queried once (hipGetDeviceProperties is a slow host call; this entry point runs every tick)
+  static int cu_cache[64] = {0};
+  int cus = (device >= 0 && device < 64) ? cu_cache[device] : 0;
+  if (cus <= 0) {
+    hipDeviceProp_t prop;
+    cus = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
+    if (device >= 0 && device < 64) cu_cache[device] = cus;
+  }
   const int per_cu = (int)((160 * 1024) / (sizeof(double) * LDS_DOUBLES + 64));       // LDS-limited residency
   int grid = cus * (per_cu < 1 ? 1 : per_cu);
   if (B < grid) grid = B;

@@ -75,3 +75,17 @@ def solve_sharded(solve_fn, records, N, nu, group=None, gather="feedback"):
     packed = torch.cat((payload, status.to(payload.dtype)[:, None], iters.to(payload.dtype)[:, None]), dim=1)
     full = gather_shards(packed, B, group)
     return full[:, :-2], full[:, -2].to(torch.int32), full[:, -1].to(torch.int32)
+
+
+def gather_rank_stats(values, group=None, device=None):
+    """(world, len(values)) fp64 on the host: a few scalars of every rank (step time, gather time) on every rank, so
+    that the one JSON line of a multi-GPU run shows skew between ranks next to the cost of the collective."""
+    v = torch.tensor([float(x) for x in values], dtype=torch.float64)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return v[None, :]
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) != "gloo":
+        v = v.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    out = torch.empty((world, v.numel()), dtype=torch.float64, device=v.device)
+    dist.all_gather_into_tensor(out, v[None, :].contiguous(), group=group)
+    return out.cpu()

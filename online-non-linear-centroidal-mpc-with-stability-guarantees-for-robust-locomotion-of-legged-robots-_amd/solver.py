@@ -85,8 +85,10 @@ class BatchedCentroidalMPC:
             if t is not None and not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
                                       and tuple(t.shape) == (B, sp.nstate) and t.device == self.device):
                 raise ValueError(f"{name} must be a contiguous fp64 CUDA tensor of shape (B, {sp.nstate})")
-        if state is not None and state_out is not None and state.data_ptr() == state_out.data_ptr():
-            raise ValueError("state and state_out must be different tensors")
+        if state is not None and state_out is not None:
+            a, b, nb = state.data_ptr(), state_out.data_ptr(), B * sp.nstate * 8
+            if a < b + nb and b < a + nb:                      # (views of one buffer included; the C entry point checks too)
+                raise ValueError("state and state_out must not overlap")
         if out is None:
             out = torch.empty((B, sp.nsol), dtype=torch.float64, device=records.device)
         status = torch.empty(B, dtype=torch.int32, device=records.device)

@@ -134,11 +134,13 @@ CONFIGS = {
 }
 
 
-def make_workload(name, B=None, N=None, scale=1.0, rate=1):
+def make_workload(name, B=None, N=None, scale=1.0, rate=1, seed=None):
     """(spec, records (B, nrec) numpy) for one of the BASELINE synthetic configs.
+    seed = None: the configuration's own seed; another value draws a fresh batch of the same distribution.
     rate = 10 is the reference's ``mpc_rate == 10`` variant: delta = 0.1 s, k1, k2 = 5, 0.2, no force-rate
     cost (:11, :27-31, :339-341), references sampled every tenth tick (:548-600)."""
-    seed, N0, nv, payload, B0 = CONFIGS[name]
+    seed0, N0, nv, payload, B0 = CONFIGS[name]
+    seed = seed0 if seed is None else seed
     B = B0 if B is None else B
     N = N0 if N is None else N
     sc = scene()
@@ -182,3 +184,32 @@ def walk_records(spec, ticks, hw=None, theta_hat=None):
     th = np.zeros((B, 3)) if theta_hat is None else np.asarray(theta_hat, dtype=np.float64)
     return sc.build_records(spec, t, com, dcom, hw, th, np.zeros(B), np.zeros(B),
                             np.full(B, HRP4_MASS), np.full(B, 0.5))
+
+
+WBC_ND, WBC_NC = 30, 12           # dofs and contact-wrench dimensions of the whole-body QP (code/inverse_dynamics.py:30-66)
+
+
+def wbc_synthetic(B, seed=0, contact="ds", mass=HRP4_MASS, g=9.81):
+    """Synthetic instances of the size and structure of the reference's QP for HRP-4 (30 dofs): task Jacobians of the
+    shapes of :46-51 with random entries, a positive definite mass matrix with the robot's total mass on the base
+    translation, gravity on the base, contact Jacobians [.. foot wrench ..] scaled by the contact flags (:109)."""
+    rng = np.random.default_rng(seed)
+    Hq = np.zeros((B, WBC_ND, WBC_ND)); Fq = np.zeros((B, WBC_ND)); M = np.zeros((B, WBC_ND, WBC_ND)); h = np.zeros((B, WBC_ND)); Jc = np.zeros((B, WBC_NC, WBC_ND))
+    sel = np.zeros(WBC_ND); sel[18:30] = 1.0                         # "redundant dofs" of the joint task
+    weights = {'lfoot': 1.0, 'rfoot': 1.0, 'com': 1.0, 'torso': 1.0, 'base': 1.0}
+    rows = {'lfoot': 6, 'rfoot': 6, 'com': 3, 'torso': 3, 'base': 3}
+    for b in range(B):
+        Jt = {k: rng.normal(0, 0.4, size=(r, WBC_ND)) for k, r in rows.items()}
+        for k in ('lfoot', 'rfoot'):
+            Jt[k][:, :6] += np.eye(6)                             # feet move with the floating base
+        Jt['com'][:, 3:6] += np.eye(3)
+        Hb = sum(weights[k] * Jt[k].T @ Jt[k] for k in rows) + 0.1 * np.diag(sel)
+        acc = {k: rng.normal(0, 1.0, size=r) for k, r in rows.items()}
+        Fb = -sum(weights[k] * Jt[k].T @ acc[k] for k in rows) - 0.1 * sel * rng.normal(0, 1.0, size=WBC_ND)
+        L = rng.normal(0, 0.15, size=(WBC_ND, WBC_ND))
+        Mb = L @ L.T + np.diag(np.concatenate([np.full(3, 2.0), np.full(3, mass), rng.uniform(0.05, 1.0, WBC_ND - 6)]))
+        hb = rng.normal(0, 2.0, size=WBC_ND); hb[5] += mass * g      # gravity on the base translation (z)
+        cl, cr = contact in ("ds", "lfoot"), contact in ("ds", "rfoot")
+        Jcb = np.vstack([cl * Jt['lfoot'], cr * Jt['rfoot']])
+        Hq[b], Fq[b], M[b], h[b], Jc[b] = Hb, Fb, Mb, hb, Jcb
+    return Hq, Fq, M, h, Jc

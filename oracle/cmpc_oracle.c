@@ -77,6 +77,9 @@
  * 10.4 / 8 / 24; 1e-7 (level 1.8e-7, the last one before the final barrier value): 10.0 / 7 / 1.  From a level mu the
  * complementarity products of weakly active rows shrink by at most 4x per Newton step (the ds*dz term), so the tail
  * costs log4(mu / 1e-9) iterations whatever the schedule: the lowest interior level wins. */
+#ifndef RESUME_RECENTRE_ITERS
+#define RESUME_RECENTRE_ITERS 20     /* a resumed solve still at the state's barrier value after this many iterations gives up */
+#endif
 #ifndef MU_WARM
 #define MU_WARM 1e-7
 #endif
@@ -631,8 +634,15 @@ static void write_solution(const prob_t *P, const work_t *W, double *out) {
 }
 
 /* One interior-point solve.  out: X then U (reference layout). */
+static void solve_one_capped(const cmpc_spec *sp, const double *rec, const double *warm, double *out,
+                             stats_t *st, int verbose, double *full, const double *state_in, double *state_out, int cap);
 static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm, double *out,
                       stats_t *st, int verbose, double *full, const double *state_in, double *state_out) {
+  solve_one_capped(sp, rec, warm, out, st, verbose, full, state_in, state_out, sp->max_iter);
+}
+/* cap: iteration budget of this attempt (a resumed attempt and the plain one that may follow it share max_iter) */
+static void solve_one_capped(const cmpc_spec *sp, const double *rec, const double *warm, double *out,
+                             stats_t *st, int verbose, double *full, const double *state_in, double *state_out, int cap) {
   prob_t Pb; prob_init(&Pb, sp, rec);
   const prob_t *P = &Pb;
   const int N = P->N, nx = P->nx, nu = P->nu, nz = P->nz, ni = P->ni;
@@ -697,7 +707,7 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
   double dbg_ap = 0, dbg_ad = 0;
   double kkt = INFINITY;
   double *xn = (double *)malloc(sizeof(double) * nx);
-  for (it = 0; it <= sp->max_iter; ++it) {
+  for (it = 0; it <= cap; ++it) {
     /* ---- linearise every stage ---- */
     double e_d = 0, e_p = 0, e_c = 0, e_cmu = 0, sum_mult = 0, fobj = 0;
     int n_mult = 0, dbg_k = -1, dbg_j = -1;
@@ -772,10 +782,15 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
       }
     }
     if (polish == 0) { st->status = CMPC_CONVERGED; break; }
-    if (it == sp->max_iter || !isfinite(kkt) || n_stall >= STALL_ITERS) {
+    /* a resumed solve that is still at the state's barrier value after RESUME_RECENTRE_ITERS iterations: the state does
+     * not fit this tick's problem (a push, a re-planned contact); give up here instead of crawling to the cap -- the
+     * plain solve follows with the rest of the budget (round-3 advisor: one stale state stretched a closed-loop launch
+     * to twice the longest cold solve) */
+    const int stale = resume && it >= RESUME_RECENTRE_ITERS && polish < 0 && mu == state_in[o_mu];
+    if (it == cap || !isfinite(kkt) || n_stall >= STALL_ITERS || stale) {
       if (polish >= 0) st->status = CMPC_CONVERGED;               /* (cap reached inside the polish) */
-      else if (kkt_saved <= acc_tol) { st->status = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = 1; }
-      else st->status = (it == sp->max_iter) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
+      else if (kkt_saved <= acc_tol && !stale) { st->status = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = 1; }
+      else st->status = (it == cap && !stale) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
       break;
     }
     if (polish > 0) --polish;
@@ -889,8 +904,10 @@ static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm
     /* the resumed solve got nowhere (the state was too far from this tick's problem): start again the plain way;
      * the iterations of both attempts are reported */
     const int spent = st->iters;
-    solve_one(sp, rec, warm, out, st, verbose, full, NULL, state_out);
-    st->iters += spent;
+    if (spent < sp->max_iter) {                /* both attempts together stay within max_iter (+ 1: `iters` <= max_iter + 1) */
+      solve_one_capped(sp, rec, warm, out, st, verbose, full, NULL, state_out, sp->max_iter - spent);
+      st->iters += spent;
+    }
   }
   /* first spare word of the state: what this solve took (the kernel's launch queues its instances by it) */
   if (state_out) state_out[o_mu + 1] = (double)st->iters;

@@ -137,29 +137,3 @@ def kkt_full(Hq, Fq, M, h, Jc, d, mu_f, qdd, tau, f):
     z = sol[2 * n:]
     return dict(stationarity=res / max(1.0, np.abs(g).max()), equality=np.abs(Aeq @ x - beq).max(),
                 ineq_violation=max(gi.max(), 0.0), n_active=int(act.sum()), z_min=float(z.min()) if z.size else 0.0)
-
-
-def synthetic(B, seed=0, contact="ds", mass=40.05487735, g=9.81):
-    """Synthetic instances of the size and structure of the reference's QP for HRP-4 (30 dofs): task Jacobians of the
-    shapes of :46-51 with random entries, a positive definite mass matrix with the robot's total mass on the base
-    translation, gravity on the base, contact Jacobians [.. foot wrench ..] scaled by the contact flags (:109)."""
-    rng = np.random.default_rng(seed)
-    Hq = np.zeros((B, ND, ND)); Fq = np.zeros((B, ND)); M = np.zeros((B, ND, ND)); h = np.zeros((B, ND)); Jc = np.zeros((B, NC, ND))
-    sel = np.zeros(ND); sel[18:30] = 1.0                         # "redundant dofs" of the joint task
-    weights = {'lfoot': 1.0, 'rfoot': 1.0, 'com': 1.0, 'torso': 1.0, 'base': 1.0}
-    rows = {'lfoot': 6, 'rfoot': 6, 'com': 3, 'torso': 3, 'base': 3}
-    for b in range(B):
-        Jt = {k: rng.normal(0, 0.4, size=(r, ND)) for k, r in rows.items()}
-        for k in ('lfoot', 'rfoot'):
-            Jt[k][:, :6] += np.eye(6)                             # feet move with the floating base
-        Jt['com'][:, 3:6] += np.eye(3)
-        Hb = sum(weights[k] * Jt[k].T @ Jt[k] for k in rows) + 0.1 * np.diag(sel)
-        acc = {k: rng.normal(0, 1.0, size=r) for k, r in rows.items()}
-        Fb = -sum(weights[k] * Jt[k].T @ acc[k] for k in rows) - 0.1 * sel * rng.normal(0, 1.0, size=ND)
-        L = rng.normal(0, 0.15, size=(ND, ND))
-        Mb = L @ L.T + np.diag(np.concatenate([np.full(3, 2.0), np.full(3, mass), rng.uniform(0.05, 1.0, ND - 6)]))
-        hb = rng.normal(0, 2.0, size=ND); hb[5] += mass * g      # gravity on the base translation (z)
-        cl, cr = contact in ("ds", "lfoot"), contact in ("ds", "rfoot")
-        Jcb = np.vstack([cl * Jt['lfoot'], cr * Jt['rfoot']])
-        Hq[b], Fq[b], M[b], h[b], Jc[b] = Hb, Fb, Mb, hb, Jcb
-    return Hq, Fq, M, h, Jc

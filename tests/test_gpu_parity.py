@@ -307,6 +307,44 @@ def test_device_record_builder_is_bit_exact(gpu, scene):
     assert bld.build(spec, bad[:0], torch.zeros((0, 16), dtype=torch.float64, device="cuda:0")).shape == (0, spec.nrec)
 
 
+def test_device_builder_serves_the_reference_generator_tables(gpu):
+    """SURVEY 8f row 3 (code/functions.py:11-124, :129-248): the CoM reference generator stays on the host (it runs once,
+    offline), and what the hot path consumes of it are the nine per-tick lists.  Fed with the lists of a walk that is
+    NOT the shipped one (other velocity commands, so another plan, other spline coefficients), the device builder must
+    hand every solver record exactly the words `functions.references` returned for ticks t + 1 ... t + N -- read here
+    straight from the generator's dict, not from the scene's table -- and, read back tick by tick, the reference is
+    still the generator's C2 quintic spline (no jump in position, velocity or acceleration at the knots)."""
+    from cmpc_amd import workloads as wl
+    from cmpc_amd.functions import references
+    from cmpc_amd.footstep_planner_vertices import FootstepPlanner
+    from cmpc_amd.foot_trajectory_generator import FootTrajectoryGenerator
+    from cmpc_amd.solver import DeviceRecordBuilder
+    sc = wl.Scene()
+    vref = [(0.1, 0.0, 0)] * 6 + [(0.2, 0.0, 0)] * 6 + [(0.05, 0.0, 0)] * 5 + [(0.0, 0, 0)] * 3
+    sc.planner = FootstepPlanner(vref, wl.LFOOT0, wl.RFOOT0, sc.params)
+    sc.ftg = FootTrajectoryGenerator(sc.initial, sc.planner, sc.params)
+    sc.com_ref = references(sc.ftg, sc.planner)
+    sc.refresh_tables()
+    assert not np.array_equal(sc.com_tab[:1500], wl.scene().com_tab[:1500])        # really another walk
+    keys = ('pos_x', 'pos_y', 'pos_z', 'vel_x', 'vel_y', 'vel_z', 'acc_x', 'acc_y', 'acc_z')
+    gen = np.stack([np.asarray(sc.com_ref[k], dtype=np.float64)[:sc.T] for k in keys], axis=1)
+    bld = DeviceRecordBuilder(sc, device="cuda:0")
+    for N in (10, 20):
+        spec = ProblemSpec(N=N)
+        t = np.arange(0, sc.t_max(N) + 1, dtype=np.int32)                           # every admissible tick
+        state = np.zeros((t.shape[0], 16))
+        got = bld.build(spec, torch.from_numpy(t).to("cuda:0"), torch.from_numpy(state).to("cuda:0")).cpu().numpy()
+        st = got[:, 24:].reshape(t.shape[0], N, 19)
+        want = gen[t[:, None] + 1 + np.arange(N)[None, :]]                          # ticks t + (1 + i), i < N (:548-577)
+        assert np.array_equal(st[:, :, 0:9], want)
+    # the table as the device serves it, tick by tick (stage 0 of the record of tick t is tick t + 1)
+    tab = st[:, 0, 0:9]
+    for a in (0, 1):                           # x, y: no jump at the knots in position, velocity (per step time, :222) or
+        pos, vel, acc = tab[:, a], tab[:, 3 + a], tab[:, 6 + a]                   # acceleration (per tick^2, :243)
+        assert np.abs(np.diff(pos)).max() < 3e-3 and np.abs(np.diff(vel)).max() < 1e-2 and np.abs(np.diff(acc)).max() < 1e-4
+    assert np.all(tab[:, 2] == 0.72) and np.all(tab[:, 5] == 0.0) and np.all(tab[:, 8] == 0.0)   # functions.py:97-99
+
+
 def test_batched_closed_loop_rollout(gpu, scene):
     """Config-1 analogue as parallel rollouts: the nominal walk through the first step (double support,
     lift-off, early single support) with measured-momentum-like perturbations, and a pushed copy."""

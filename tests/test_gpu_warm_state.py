@@ -88,7 +88,8 @@ def test_state_edge_cases_stale_state_nan_record_and_horizon_limits(oracle):
     f_b = oracle.evaluate(cs, rec_at(640, 0.08)[0], b[0].cpu().numpy(), uprox=up)[0]
     f_c = oracle.evaluate(cs, rec_at(640, 0.08)[0], c[0].cpu().numpy(), uprox=up)[0]
     assert abs(f_b - f_c) <= 1e-7 * abs(f_c) and rel_inf(b.cpu().numpy(), c.cpu().numpy())[0] < 1e-3
-    assert int(it_b[0]) <= int(it_c[0]) + 60                                             # (fallback: both attempts are counted)
+    # fallback: both attempts are counted and share max_iter; a state that does not fit is given up after twenty iterations
+    assert int(it_b[0]) <= spec.max_iter + 1 and int(it_b[0]) <= int(it_c[0]) + 22
     # (b)
     bad = rec_at(300); bad[0, 30] = np.nan
     s3 = solver.new_state(1)
@@ -139,3 +140,26 @@ def test_state_path_of_the_eight_vertex_two_wave_kernel(oracle):
     for i in (0, 333, 639):
         ci, _, it_i, _ = solver.solve(d[i:i + 1], warm=b[i:i + 1], state=s2[i:i + 1].clone(), state_out=solver.new_state(1))
         assert torch.equal(ci[0], c[i]) and int(it_i[0]) == int(it_c[i])
+
+
+def test_state_in_and_state_out_must_not_overlap():
+    """The kernel invalidates state_out before it reads state_in: overlapping ranges are refused by the C entry point
+    (views of one buffer included), not solved from a half-overwritten state."""
+    import ctypes
+    from cmpc_amd import capi
+    spec, rec = wl.make_workload("perturbed", B=4, N=10)
+    solver = BatchedCentroidalMPC(spec, device="cuda:0")
+    d = torch.from_numpy(rec).cuda()
+    buf = torch.zeros((5, spec.nstate), dtype=torch.float64, device="cuda:0")
+    with pytest.raises(ValueError, match="overlap"):
+        solver.solve(d, state=buf[0:4], state_out=buf[1:5])
+    out = torch.empty((4, spec.nsol), dtype=torch.float64, device="cuda:0")
+    st, it = torch.empty(4, dtype=torch.int32, device="cuda:0"), torch.empty(4, dtype=torch.int32, device="cuda:0")
+    kk = torch.empty(4, dtype=torch.float64, device="cuda:0")
+    lib = capi.load()
+    rc = lib.cmpc_solve_batch_state(solver._h, 4, d.data_ptr(), None, buf[0:4].data_ptr(), out.data_ptr(), buf[1:5].data_ptr(),
+                                    st.data_ptr(), it.data_ptr(), kk.data_ptr(), None)
+    assert rc != 0 and b"overlap" in lib.cmpc_last_error(solver._h)
+    rc = lib.cmpc_solve_batch_state(solver._h, 4, d.data_ptr(), None, buf[0:4].data_ptr(), out.data_ptr(), buf[0:4].data_ptr(),
+                                    st.data_ptr(), it.data_ptr(), kk.data_ptr(), None)
+    assert rc != 0

@@ -105,3 +105,30 @@ def test_device_source_resumes_like_the_oracle(emu, oracle):
     assert np.abs(it_e - it_o).max() <= 2 and abs(it_e.sum() - it_o.sum()) <= 3, (it_e, it_o)   # (end game: rounding order)
     assert rel_inf(sol_e, sol_o).max() < 1e-6
     assert it_e[1:].mean() < it_e[0]
+
+
+def test_stale_state_is_given_up_early_and_the_two_attempts_share_the_budget(oracle):
+    """A state written for a tick far away (another contact phase, pushed CoM) does not fit this tick's problem: the
+    resumed attempt is abandoned once it has stayed at the state's barrier value for twenty iterations (or ended
+    without a usable point) and the plain solve follows with what is left of max_iter -- `iters` counts both and never
+    exceeds max_iter + 1 (include/cmpc.h).  Round 3 let the resumed attempt crawl to the cap first."""
+    sc = wl.scene()
+    spec = ProblemSpec(N=10)
+
+    def rec_at(t, push=0.0):
+        com, dcom = sc.nominal_state(np.array([t]))
+        return sc.build_records(spec, np.array([t]), com, dcom + push, HW[t][None], np.zeros((1, 3)), np.zeros(1),
+                                np.zeros(1), np.full(1, wl.HRP4_MASS), np.full(1, 0.5))
+    for max_iter in (100, 30):
+        cs = oracle.default_spec(N=10, nv=4, tol=1e-8, max_iter=max_iter)
+        a, s1, st_a, _, _ = oracle.solve_batch_state(cs, rec_at(120))
+        assert st_a[0] == 0
+        for t, push in ((640, 0.08), (655, -0.1), (1130, 0.05)):
+            far = rec_at(t, push)
+            b, _, st_b, it_b, _ = oracle.solve_batch_state(cs, far, warm=a, state=s1)
+            c, st_c, it_c, _ = oracle.solve_batch(cs, far, warm=a)
+            assert it_b[0] <= max_iter + 1, (t, it_b, max_iter)
+            if max_iter == 100:
+                assert st_b[0] in (0, 3) and st_c[0] in (0, 3)
+                assert it_b[0] <= it_c[0] + 22, (t, it_b, it_c)
+                assert rel_inf(b, c)[0] < 1e-3

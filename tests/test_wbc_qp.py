@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from cmpc_amd import capi, wbc
+from cmpc_amd import capi, wbc, workloads as wl
 from oracle import wbc_qp_oracle as wq
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("contact", ["ds", "lfoot", "rfoot"])
 def test_oracle_solution_satisfies_the_reference_statement(contact):
-    Hq, Fq, M, h, Jc = wq.synthetic(6, seed=3, contact=contact)
+    Hq, Fq, M, h, Jc = wl.wbc_synthetic(6, seed=3, contact=contact)
     for b in range(6):
         r = wq.solve(Hq[b], Fq[b], M[b], h[b], Jc[b], 0.05, 0.5)
         assert r["status"] == 0 and r["iters"] <= 40
@@ -37,7 +37,7 @@ def test_oracle_solution_satisfies_the_reference_statement(contact):
 
 def test_solution_is_the_minimiser_among_feasible_perturbations():
     """Independent of the KKT algebra: no feasible point nearby has a lower cost."""
-    Hq, Fq, M, h, Jc = wq.synthetic(1, seed=11)
+    Hq, Fq, M, h, Jc = wl.wbc_synthetic(1, seed=11)
     r = wq.solve(Hq[0], Fq[0], M[0], h[0], Jc[0], 0.05, 0.5)
     cost = lambda q, f: 0.5 * q @ Hq[0] @ q + Fq[0] @ q + 0.5 * wq.F_REG * f @ f
     base = cost(r["qdd"], r["f"])
@@ -82,7 +82,7 @@ def test_header_symbols_are_exported():
 @pytest.mark.gpu
 @pytest.mark.parametrize("contact,B", [("ds", 300), ("lfoot", 64), ("rfoot", 64)])
 def test_hip_kernel_matches_the_oracle(contact, B):
-    Hq, Fq, M, h, Jc = wq.synthetic(B, seed=21, contact=contact)
+    Hq, Fq, M, h, Jc = wl.wbc_synthetic(B, seed=21, contact=contact)
     ref = wq.solve_batch(Hq[:48], Fq[:48], M[:48], h[:48], Jc[:48], 0.05, 0.5)
     qp = wbc.BatchedInverseDynamicsQP(foot_size=0.1, mu=0.5, device="cuda:0")
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -104,3 +104,23 @@ def test_hip_kernel_matches_the_oracle(contact, B):
     # batch composition does not matter (instances are independent)
     t2 = qp.solve(dev(Hq[7:9]), dev(Fq[7:9]), dev(M[7:9]), dev(h[7:9]), dev(Jc[7:9]))[0].cpu().numpy()
     assert np.array_equal(t2, tau[7:9])
+
+
+@pytest.mark.gpu
+def test_hip_kernel_failure_path_returns_zeros_like_the_reference():
+    """code/utils.py:85-92: QPSolver.solve returns zeros when the solver fails.  An indefinite task Hessian (wrong-inertia
+    pivot) and a NaN input (non-finite KKT error) must end with status 2 and finite, zero outputs; the good instances
+    of the same batch are untouched."""
+    Hq, Fq, M, h, Jc = wl.wbc_synthetic(4, seed=5)
+    Hq[1] = -Hq[1]                                  # indefinite: the first pivot is negative
+    Fq[2, 3] = np.nan                               # non-finite residual
+    qp = wbc.BatchedInverseDynamicsQP(foot_size=0.1, mu=0.5, device="cuda:0")
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    tau, qdd, f, st, it = qp.solve(dev(Hq), dev(Fq), dev(M), dev(h), dev(Jc))
+    torch.cuda.synchronize()
+    assert st.tolist() == [0, 2, 2, 0]
+    for b in (1, 2):
+        assert float(tau[b].abs().max()) == 0.0 and float(qdd[b].abs().max()) == 0.0 and float(f[b].abs().max()) == 0.0
+    assert torch.isfinite(tau).all() and torch.isfinite(qdd).all() and torch.isfinite(f).all()
+    ref = wq.solve(Hq[3], Fq[3], M[3], h[3], Jc[3], 0.05, 0.5)
+    assert np.abs(qdd[3].cpu().numpy() - ref["qdd"]).max() < 1e-6 * max(1.0, np.abs(ref["qdd"]).max())
