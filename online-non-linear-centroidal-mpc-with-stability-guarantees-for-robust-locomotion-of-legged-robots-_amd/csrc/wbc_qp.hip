@@ -157,8 +157,10 @@ __global__ void __launch_bounds__(64) wbc_qp_kernel(int B, const double *__restr
       const double e_c = wave_max((lane < NI) ? fabs(sl * zl) : 0.0) / sd;
       const double e_cmu = wave_max((lane < NI) ? fabs(sl * zl - mu) : 0.0) / sd;
       const double kkt = fmax(fmax(e_d, e_p), e_c);
+      // (fmax drops NaNs: a NaN residual must be looked for, or a NaN input "converges" with NaN outputs)
+      const double nonfinite = wave_max((isfinite(rd) && isfinite(rp) && isfinite(rg) && isfinite(sl * zl)) ? 0.0 : 1.0);
+      if (nonfinite != 0.0 || !(kkt < INFINITY)) { st = 2; break; }
       if (kkt <= tol) { st = 0; break; }
-      if (!(kkt < INFINITY)) { st = 2; break; }
       if (it == max_iter) break;
       while (mu > tol / 10 && fmax(fmax(e_d, e_p), e_cmu) < 10 * mu) mu = fmax(tol / 10, fmin(0.1 * mu, mu * sqrt(mu)));
       // ---- barrier weights, right-hand side

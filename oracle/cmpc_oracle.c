@@ -53,6 +53,9 @@
 #define POLISH_ITERS 1
 /* barrier schedule: start value and linear decrease factor (tuned on the synthetic configs: a large
  * start value centres the first iterates; 0.1 -> 100 cut the mean iteration count from 33 to 23) */
+#ifndef COLD_ROLLOUT             /* 1: cold start rolled out under the initial inputs (see initial_point) */
+#define COLD_ROLLOUT 0
+#endif
 #ifndef MU_INIT                  /* (-D overrides: tuning experiments only, tools/tune_schedule.py) */
 #define MU_INIT 100.0
 #endif
@@ -623,6 +626,18 @@ static void initial_point(const prob_t *P, work_t *W, const double *warm, const 
   memcpy(W->x, P->rec, sizeof(double) * CMPC_NX);          /* x_0 is data */
   for (int k = 1; k <= N; ++k)
     for (int j = 0; j < 2 * nv; ++j) W->x[(size_t)k * nx + CMPC_NX + j] = W->u[(size_t)(k - 1) * nu + 3 * j + 2];
+#if COLD_ROLLOUT
+  if (!warm) {
+    /* dynamics-consistent cold start: the states are rolled out from x_0 under the initial inputs, x_{k+1} = F(x_k, u_k),
+     * instead of standing still at x_0 (zero dynamics defect at the first iterate) */
+    double *xn = (double *)malloc(sizeof(double) * nx);
+    for (int k = 0; k < N; ++k) {
+      stage_dynamics(P, k, W->x + (size_t)k * nx, W->u + (size_t)k * nu, xn, NULL, NULL, NULL);
+      memcpy(W->x + (size_t)(k + 1) * nx, xn, sizeof(double) * nx);
+    }
+    free(xn);
+  }
+#endif
 }
 
 /* X (20 x (N+1)) then U (nu x N), the reference's layout */

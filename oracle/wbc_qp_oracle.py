@@ -61,6 +61,9 @@ def solve(Hq, Fq, M, h, Jc, d, mu_f, tol=TOL, max_iter=MAX_ITER, verbose=False):
         kkt = max(e_d, e_p, e_c)
         if verbose:
             print(f"it {it:2d} d={e_d:.2e} p={e_p:.2e} c={e_c:.2e} mu={mu:.1e}")
+        if not np.isfinite(kkt):                # NaN / Inf input: numerical failure (the kernel: status 2, zero outputs)
+            status = 2
+            break
         if kkt <= tol:
             status = 0
             break
@@ -81,9 +84,12 @@ def solve(Hq, Fq, M, h, Jc, d, mu_f, tol=TOL, max_iter=MAX_ITER, verbose=False):
         ap = min(1.0, (tau_ * s[ds < 0] / -ds[ds < 0]).min()) if (ds < 0).any() else 1.0
         ad = min(1.0, (tau_ * z[dz < 0] / -dz[dz < 0]).min()) if (dz < 0).any() else 1.0
         x = x + ap * dx; s = s + ap * ds; nu = nu + ap * (nu_new - nu); z = z + ad * dz
+    if status != 0:                             # the reference's QPSolver.solve returns zeros on failure (code/utils.py:85-92)
+        x = np.zeros(n)
     qdd, f = x[:ND], x[ND:]
     tau = np.zeros(ND)
-    tau[NB:] = M[NB:, :] @ qdd + h[NB:] - Jc[:, NB:].T @ f
+    if status == 0:
+        tau[NB:] = M[NB:, :] @ qdd + h[NB:] - Jc[:, NB:].T @ f
     return dict(qdd=qdd, f=f, tau=tau, nu=nu, s=s, z=z, status=status, iters=it, kkt=kkt)
 
 

@@ -122,5 +122,7 @@ def test_hip_kernel_failure_path_returns_zeros_like_the_reference():
     for b in (1, 2):
         assert float(tau[b].abs().max()) == 0.0 and float(qdd[b].abs().max()) == 0.0 and float(f[b].abs().max()) == 0.0
     assert torch.isfinite(tau).all() and torch.isfinite(qdd).all() and torch.isfinite(f).all()
+    bad = wq.solve(Hq[2], Fq[2], M[2], h[2], Jc[2], 0.05, 0.5)               # the oracle takes the same exit
+    assert bad["status"] == 2 and not bad["qdd"].any() and not bad["tau"].any()
     ref = wq.solve(Hq[3], Fq[3], M[3], h[3], Jc[3], 0.05, 0.5)
     assert np.abs(qdd[3].cpu().numpy() - ref["qdd"]).max() < 1e-6 * max(1.0, np.abs(ref["qdd"]).max())
