@@ -17,7 +17,7 @@ def _newer(target, sources):
 def build_hip(force=False, verbose=False):
     src = os.path.join(PKG, "csrc", "cmpc_hip.hip")
     wbc = os.path.join(PKG, "csrc", "wbc_qp.hip")          # batched whole-body QP (include/cmpc_wbc.h), same library
-    deps = [src, wbc, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"),
+    deps = [src, wbc, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"), os.path.join(PKG, "csrc", "cmpc_order_fit.h"),
             os.path.join(ROOT, "include", "cmpc.h"), os.path.join(ROOT, "include", "cmpc_wbc.h")]
     out = os.path.join(PKG, "libcmpc_amd.so")
     if force or _newer(out, deps):

@@ -12,6 +12,7 @@
 #include <string>
 
 #include "cmpc_kernel.hpp"
+#include "cmpc_order_fit.h"
 
 // Register budget: 2 waves per SIMD (<= 256 VGPR+AGPR) lets a CU hold 5 single-wave workgroups
 // (LDS-limited) instead of 4 (one per SIMD).
@@ -51,8 +52,9 @@ __device__ __forceinline__ int cmpc_order_bucket(const double *__restrict__ r, i
   const double ty = both ? 0.5 * (r[14] + r[18]) : (gl0 != 0.0) ? r[14] : r[18];
   const double d2 = (dx - tx) * (dx - tx) + (dy - ty) * (dy - ty);
   const double hw = sqrt(r[6] * r[6] + r[7] * r[7] + r[8] * r[8]);
-  const double its = 9.964 + 3.656 * (first < N) + 0.158 * first + 1.916 * (gl0 + gr0) + 13.359 * sqrt(d2) + 170.148 * d2 + 0.075 * hw;
-  const double b = 2.0 * (its - 10.0);                                       // buckets of half an iteration from 10 up
+  const double its = CMPC_ORDER_C0 + CMPC_ORDER_C_SWITCH * (first < N) + CMPC_ORDER_C_FIRST * first + CMPC_ORDER_C_FEET * (gl0 + gr0) +
+                     CMPC_ORDER_C_D * sqrt(d2) + CMPC_ORDER_C_D2 * d2 + CMPC_ORDER_C_HW * hw;      // csrc/cmpc_order_fit.h
+  const double b = 2.0 * (its - CMPC_ORDER_BUCKET_ORIGIN);                   // buckets of half an iteration
   return (b > 0.0) ? ((b < ORDER_BUCKETS - 1) ? (int)b : ORDER_BUCKETS - 1) : 0;   // (a NaN record lands in bucket 0)
 }
 
@@ -101,7 +103,10 @@ __global__ void __launch_bounds__(64 * NW, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) 
   double *slab = ka.scratch + (size_t)blockIdx.x * ka.scratch_stride;
   const size_t nrec = CMPC_NREC(ka.sp.N), nsol = CMPC_NSOL(ka.sp.N, NV), nstate = CMPC_NSTATE(ka.sp.N, NV);
   for (;;) {
-    if (threadIdx.x == 0) next = atomicAdd(ticket, 1);
+    // (single-wave workgroups: the lane id from the execution mask, re-derived per instance, instead of threadIdx.x kept
+    // live -- and spilled -- across the whole solve)
+    const int tid = (NW == 1) ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : (int)threadIdx.x;
+    if (tid == 0) next = atomicAdd(ticket, 1);
     __syncthreads();
     const int tk = next;
     __syncthreads();

@@ -105,8 +105,9 @@ constexpr double ACC_FACTOR = 100.0;
 constexpr int ACC_ITERS = 8;
 constexpr double STALL_STEP = 1e-7;
 constexpr int STALL_ITERS = 6;
-// no progress at the final barrier value: NOPROG_ITERS iterations without halving the best KKT error seen
-// there; the run then ends as CMPC_ACCEPTABLE as soon as the error is within spec.acc_tol (see the oracle)
+// no progress at a barrier value: NOPROG_ITERS iterations without halving the best error of that barrier problem
+// (the KKT error at the final value); the run then ends as CMPC_ACCEPTABLE once a point within spec.acc_tol is in hand
+// (see the oracle)
 constexpr int NOPROG_ITERS = 12;
 // smallest pivot accepted by the stage factorisation: max(PIV_MIN, PIV_FRAC * delta) (see the oracle)
 constexpr double PIV_MIN = 1e-8;
@@ -119,6 +120,8 @@ constexpr double MU_FACTOR = 0.1;
 // warm start of the interior point method: the solver state is the iterate at the last barrier value >= MU_WARM
 // (see the oracle for the choice of the level)
 constexpr double MU_WARM = 1e-7;
+// cold start: states rolled out from x_0 under the initial inputs (see the oracle)
+constexpr bool COLD_ROLLOUT = true;
 // a resumed solve that has not left the state's barrier value after this many iterations gives up (the state was too far
 // from this tick's problem) and the plain solve follows, with what is left of the iteration budget (see the oracle)
 constexpr int RESUME_RECENTRE_ITERS = 20;
@@ -303,6 +306,9 @@ template <int NV, int NW = 1> struct Solver {
   CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
       : ka(a), sp(a.sp), lds(l), gs{g}, rec{const_cast<double *>(r)}, N(a.sp.N), lane(CMPC_LANE) {
     if constexpr (NW > 1) wv = CMPC_WAVE_ID();
+    // (one wave per workgroup: the lane id comes from the execution mask, so that threadIdx.x need not stay live -- or be
+    // spilled -- across the instance loop)
+    if constexpr (NW == 1) CMPC_RELANE(lane);
     double *p = g + (size_t)(N + 1) * D::STAGE;
     gx = GArr{p}; p += (size_t)(N + 1) * NXA;
     glam = GArr{p}; p += (size_t)(N + 1) * NXA;
@@ -1828,6 +1834,18 @@ template <int NV, int NW = 1> struct Solver {
       gx[k * NXA + CMPC_NX + j] = gu[(k - 1) * NU + 3 * j + 2];
     }
     CMPC_SYNC_GLOBAL();
+    if (COLD_ROLLOUT && !has_warm) {
+      // dynamics-consistent cold start (see the oracle): x_{k+1} = F(x_k, u_k) under the initial inputs.  The stage loader
+      // and the geometry phase do the evaluation: with x_{k+1} zeroed in LDS the defect b = F(x, u) - x_{k+1} IS F(x, u).
+      for (int k = 0; k < N; ++k) {
+        load_stage(k);
+        if (lane < NXA) L(D::oXN1 + lane) = 0.0;
+        sync();
+        stage_geometry(k);
+        if (lane < NXA) gx[(k + 1) * NXA + lane] = L(D::oBV + lane);
+        CMPC_SYNC_GLOBAL();
+      }
+    }
   }
 
   // X (20 x (N+1)) then U (nu x N), the reference's layout.  Reads the iterate arrays as apply_step /
@@ -1866,7 +1884,7 @@ template <int NV, int NW = 1> struct Solver {
       if (resume) st_in = GArr{const_cast<double *>(state_in)};
     }
     int st = CMPC_MAX_ITER, it = 0, spent = 0;
-    int cap = sp.max_iter;                      // iteration budget of the attempt: both attempts together stay within max_iter
+    // iteration budget of an attempt: sp.max_iter - spent (both attempts together stay within max_iter)
     double kkt = INFINITY;
     // at most two attempts: a resumed solve that gets nowhere (the state was too far from this tick's problem) is
     // followed by the plain one with the rest of the budget; the iterations of both are reported (see the oracle)
@@ -1887,11 +1905,14 @@ template <int NV, int NW = 1> struct Solver {
     }
     // acceptable level; every iterate the acceptable-level counter counts is also saved (see the oracle).  Formed
     // where they are used (two instructions) instead of being kept live across the solve.
-    auto acc_tol = [&]() { return fmax(sp.acc_tol, tol); };
-    auto save_tol = [&]() { return fmax(fmax(sp.acc_tol, tol), ACC_FACTOR * tol); };
+    // (the copy of the kernel argument is made opaque at every use: hoisted to kernel entry it sat in a vector register
+    // pair through the whole solve and was spilled)
+    auto acc_raw = [&]() { double a = sp.acc_tol; CMPC_OPAQUE_D(a); return a; };
+    auto acc_tol = [&]() { return fmax(acc_raw(), tol); };
+    auto save_tol = [&]() { return fmax(fmax(acc_raw(), tol), ACC_FACTOR * tol); };
     initial_point(resume ? state_in : warm, warm, resume);
     CMPC_TICK_RESET();
-    for (it = 0; it <= cap; ++it) {
+    for (it = 0; it <= sp.max_iter - spent; ++it) {
       double reg = 0.0;
       Err er;
       bool fail = false;
@@ -1912,6 +1933,7 @@ template <int NV, int NW = 1> struct Solver {
       if (lane == 0 && getenv("CMPC_EMU_TRACE"))
         printf("it %3d d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e\n", it, e_d / sd, e_p, e_c / sd, mu, reg);
 #endif
+      const double ebar = fmax(fmax(e_d / sd, e_p), e_cmu / sd);   // error of the barrier problem at mu
       double ks = kkt_saved, kb = kkt_best;     // cold state: every lane reads before any lane writes
       sync();
       if (polish >= 0 && kkt > ACC_FACTOR * tol) {
@@ -1929,8 +1951,11 @@ template <int NV, int NW = 1> struct Solver {
         } else {
           n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
           if (n_acc >= ACC_ITERS) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; break; }
-          if (mu <= tol / 10) {                  // at the final barrier value: progress watch
-            if (kkt < 0.5 * kb) { kb = kkt; kkt_best = kkt; since_best = 0; } else ++since_best;
+          {
+            // progress watch on the error of the current barrier problem (final barrier value: the KKT error); it
+            // restarts whenever the barrier value changes (see the oracle)
+            const double kw = (mu <= tol / 10) ? kkt : ebar;
+            if (kw < 0.5 * kb) { kb = kw; kkt_best = kw; since_best = 0; } else ++since_best;
             if (since_best >= NOPROG_ITERS && ks <= acc_tol()) {
               st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; break;
             }
@@ -1940,18 +1965,24 @@ template <int NV, int NW = 1> struct Solver {
       if (polish == 0) { st = CMPC_CONVERGED; break; }
       // a resumed solve still at the state's barrier value: the state does not fit this tick's problem
       const bool stale = resume && it >= RESUME_RECENTRE_ITERS && polish < 0 && mu == st_in[D::state_mu(N)];
-      if (it == cap || !(kkt < INFINITY) || n_stall >= STALL_ITERS || stale) {
+      const bool at_cap = it == sp.max_iter - spent;
+      if (at_cap || !(kkt < INFINITY) || n_stall >= STALL_ITERS || stale) {
         if (polish >= 0) st = CMPC_CONVERGED;                   // (cap reached inside the polish)
         else if (ks <= acc_tol() && !stale) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; }
-        else st = (it == cap && !stale) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
+        else st = (at_cap && !stale) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
         break;
       }
       if (reg > 0) reg_last = reg;
       if (polish > 0) --polish;
       else if (!(resume && it == 0)) {          // (a resumed solve re-centres at the state's barrier value first: see the oracle)
         const double mu_before = mu;
-        while (mu > tol / 10 && fmax(fmax(e_d / sd, e_p), e_cmu / sd) < 10 * mu)
+        while (mu > tol / 10 && ebar < 10 * mu)
           mu = fmax(tol / 10, fmin(MU_FACTOR * mu, mu * sqrt(mu)));
+        if (mu != mu_before) {                   // a new barrier problem: the progress watch restarts
+          double inf = INFINITY;
+          CMPC_OPAQUE_D(inf);
+          kkt_best = inf; since_best = 0;
+        }
         // this iterate solves the barrier problem at mu_before: the state the next tick resumes from
         if (state_out && mu_before >= MU_WARM && mu < MU_WARM && snapped == 0.0) { write_state(state_out, mu_before); snapped = 1.0; }
       }
@@ -1965,7 +1996,7 @@ template <int NV, int NW = 1> struct Solver {
     if (!use_saved) write_solution(out);
     if (!(resume && (st == CMPC_MAX_ITER || st == CMPC_NUMERICAL))) break;
     if (it >= sp.max_iter) break;               // nothing left of the budget
-    spent += it; cap = sp.max_iter - it; resume = false;
+    spent += it; resume = false;
     CMPC_SYNC_GLOBAL();
     }
     if (lane == 0) {
