@@ -55,6 +55,12 @@
 #define POLISH_ITERS 1
 /* barrier schedule: start value and linear decrease factor (tuned on the synthetic configs: a large
  * start value centres the first iterates; 0.1 -> 100 cut the mean iteration count from 33 to 23) */
+#ifndef REG_FIRST_FACTOR         /* escalation of the inertia correction: first correction of a solve, later ones (IPOPT: 100, 8) */
+#define REG_FIRST_FACTOR 100.0
+#endif
+#ifndef REG_NEXT_FACTOR
+#define REG_NEXT_FACTOR 8.0
+#endif
 #ifndef S_FLOOR                  /* floor of the initial slacks of a cold start */
 #define S_FLOOR 1e-2
 #endif
@@ -484,6 +490,7 @@ static void work_free(work_t *W) {
 
 /* Riccati backward sweep on the barrier-augmented stage QPs.  Returns 0, or -1 if a pivot of
  * R + B'PB is not positive (wrong inertia). */
+/* returns 0, or -(k + 1) when the factorisation of stage k meets a pivot below the threshold (wrong inertia) */
 static int riccati_backward(const prob_t *P, work_t *W, double reg) {
   const int N = P->N, nx = P->nx, nu = P->nu, nz = P->nz;
   double *M = W->M, *mv = W->m;
@@ -534,7 +541,7 @@ static int riccati_backward(const prob_t *P, work_t *W, double reg) {
     for (int j = 0; j < nu && rc == 0; ++j) {
       double dsum = M[j * nz + j];
       for (int q = 0; q < j; ++q) dsum -= Lm[j * nu + q] * Lm[j * nu + q];
-      if (!(dsum > piv_min)) { rc = -1; break; }
+      if (!(dsum > piv_min)) { rc = -(k + 1); break; }      /* (the failing stage, for the diagnostics) */
       double dj = sqrt(dsum);
       Lm[j * nu + j] = dj;
       for (int i = j + 1; i < nu; ++i) {
@@ -603,7 +610,7 @@ static void riccati_forward(const prob_t *P, work_t *W) {
   }
 }
 
-typedef struct { int iters, status; double kkt, mu, reg_last; int n_reg; } stats_t;
+typedef struct { int iters, status; double kkt, mu, reg_last; int n_reg; double waste; } stats_t;
 
 static void initial_point(const prob_t *P, work_t *W, const double *warm, const int *src) {
   const int N = P->N, nx = P->nx, nu = P->nu, nv = P->nv;
@@ -717,7 +724,7 @@ static void solve_one_capped(const cmpc_spec *sp, const double *rec, const doubl
   if (resume) for (int k = 0; k <= N; ++k)
     memcpy(W->lam + (size_t)k * nx, state_in + o_lam + (size_t)src[k] * nx, sizeof(double) * nx);
   int snapped = 0;
-  st->status = CMPC_MAX_ITER; st->n_reg = 0;
+  st->status = CMPC_MAX_ITER; st->n_reg = 0; st->waste = 0.0;
   int it, n_acc = 0, n_stall = 0, polish = -1, since_best = 0, use_saved = 0;
   double kkt_best = INFINITY, kkt_saved = INFINITY;
   const double acc_tol = fmax(sp->acc_tol, tol);
@@ -859,9 +866,11 @@ static void solve_one_capped(const cmpc_spec *sp, const double *rec, const doubl
     /* ---- factorise with inertia correction ---- */
     double reg = 0.0;
     int fail = 0;
-    while (riccati_backward(P, W, reg) != 0) {
+    int rb_;
+    while ((rb_ = riccati_backward(P, W, reg)) != 0) {
+      st->waste += (double)(N - (-rb_ - 1) + 1) / (N + 1);   /* share of a sweep done before the failing stage */
       if (reg == 0.0) reg = (reg_last == 0.0) ? 1e-4 : fmax(1e-20, reg_last / 3);
-      else reg *= (reg_last == 0.0) ? 100.0 : 8.0;
+      else reg *= (reg_last == 0.0) ? REG_FIRST_FACTOR : REG_NEXT_FACTOR;
       ++st->n_reg;
       if (reg > 1e20) { fail = 1; break; }
     }
@@ -978,6 +987,25 @@ int cmpc_oracle_solve_batch(const cmpc_spec *sp, int32_t B, const double *recs, 
     if (status) status[b] = st.status;
     if (iters) iters[b] = st.iters;
     if (kkt) kkt[b] = st.kkt;
+  }
+  return 0;
+}
+
+/* Diagnostic (tools/launch_model.py): as cmpc_oracle_solve_batch, plus the number of factorisation retries (inertia
+ * corrections) of every solve -- each costs the kernel up to one more matrix sweep. */
+int cmpc_oracle_solve_batch_stats(const cmpc_spec *sp, int32_t B, const double *recs, const double *warm,
+                                  double *out, int32_t *status, int32_t *iters, double *kkt, int32_t *n_reg, double *waste, int nthreads) {
+  if (sp->N < 1 || sp->N > CMPC_MAX_N || (sp->nv != 4 && sp->nv != 8)) return 1;
+  const size_t nrec = CMPC_NREC(sp->N), nsol = CMPC_NSOL(sp->N, sp->nv);
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int b = 0; b < B; ++b) {
+    stats_t st;
+    solve_one(sp, recs + b * nrec, warm ? warm + b * nsol : NULL, out + b * nsol, &st, 0, NULL, NULL, NULL);
+    status[b] = st.status; iters[b] = st.iters; kkt[b] = st.kkt; n_reg[b] = st.n_reg;
+    if (waste) waste[b] = st.waste;
   }
   return 0;
 }

@@ -119,3 +119,23 @@ def test_four_vertex_kernel_uses_no_scratch(tmp_path):
     lds = int(re.search(r"\.group_segment_fixed_size:\s*(\d+)", meta).group(1))
     assert scratch == 0 and spills == 0, (scratch, spills)
     assert 6 * ((lds + 1279) // 1280 * 1280) <= 160 * 1024      # six workgroups per CU (LDS comes in 1280-byte granules)
+
+
+def test_queue_order_coefficients_live_in_one_header():
+    """csrc/cmpc_order_fit.h is the single home of the predictor's coefficients: the kernel includes it, the host mirror
+    parses it, and nothing else spells the numbers out."""
+    from cmpc_amd import queue_order as qo, workloads as wl
+    coef, origin = qo.coefficients()
+    assert coef.shape == (7,) and 0 < origin < 40
+    hip = open(os.path.join(_b.PKG, "csrc", "cmpc_hip.hip")).read()
+    assert '#include "cmpc_order_fit.h"' in hip and "CMPC_ORDER_C_D2" in hip
+    for path in (os.path.join(ROOT, "tools", "tail_study.py"), os.path.join(_b.PKG, "csrc", "cmpc_hip.hip")):
+        assert f"{coef[5]:.3f}" not in open(path).read()
+    head = open(qo.FIT_HEADER).read()
+    assert "NOT a BASELINE seed" in head
+    for seed in (c[0] for c in wl.CONFIGS.values()):
+        assert f"--seed {seed}" not in head
+    spec, rec = wl.make_workload("randomized", B=64)
+    pred = qo.predicted_iterations(rec, spec)
+    b = qo.bucket_of(pred)
+    assert pred.shape == (64,) and b.min() >= 0 and b.max() < qo.ORDER_BUCKETS

@@ -35,18 +35,25 @@ def _solve(gpu, spec, rec, warm=None):
     return out.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), kkt.cpu().numpy()
 
 
-def _explain_outliers(oracle, cs, spec, rec, got, ref, idx, uprox=None, obj_tol=1e-7):
+def _explain_outliers(oracle, cs, spec, rec, got, ref, idx, uprox=None, obj_tol=1e-7, kkt=None, kkt_ref=None):
     """Every pair of solutions further apart than the north-star tolerance must be the SAME optimum seen from
     two points of a flat valley (curvature = the 1e-4 proximal weight against a 1e-8 KKT tolerance): equal
-    objective value, dynamics satisfied, inequalities satisfied.  Nothing else may pass."""
+    objective value, dynamics satisfied, inequalities satisfied.  Nothing else may pass.
+
+    Levels, stated from the problem: a point that met the tolerance agrees in objective to `obj_tol` and satisfies its
+    constraints to 1e-7.  A point returned at the ACCEPTABLE level carries its own final scaled KKT error kappa
+    (<= acc_tol, reported per instance): its constraint residuals are bounded by kappa, and the objective is first-order
+    sensitive to them through the multipliers, so for such a pair the objective may differ by 10 * kappa relative and
+    the residuals may reach kappa."""
     nU = 20 * (spec.N + 1)
     for i in idx:
         up = None if uprox is None else uprox[i, nU:]
+        kap = 0.0 if kkt is None else max(float(kkt[i]), float(kkt_ref[i]) if kkt_ref is not None else 0.0)
         f_g, def_g, ineq_g, act_g = oracle.evaluate(cs, rec[i], got[i], uprox=up)
         f_r, def_r, ineq_r, act_r = oracle.evaluate(cs, rec[i], ref[i], uprox=up)
-        assert abs(f_g - f_r) <= obj_tol * max(1.0, abs(f_r)), (i, f_g, f_r)
-        assert np.abs(def_g).max() < 1e-7, (i, np.abs(def_g).max())
-        assert ineq_g[act_g == 1].max() <= 1e-7, (i, ineq_g[act_g == 1].max())
+        assert abs(f_g - f_r) <= max(obj_tol, 10 * kap) * max(1.0, abs(f_r)), (i, f_g, f_r, kap)
+        assert np.abs(def_g).max() < max(1e-7, kap), (i, np.abs(def_g).max(), kap)
+        assert ineq_g[act_g == 1].max() <= max(1e-7, kap), (i, ineq_g[act_g == 1].max(), kap)
 
 
 # (median over usable pairs, median over tight pairs, q90 over tight pairs, share of pairs beyond 1e-4, objective
@@ -72,7 +79,7 @@ def test_parity_with_oracle(gpu, oracle, name, B, N, rate):
     med_all, med_tight, q90_tight, share, obj_tol = LEVELS["rate10" if rate == 10 else "long" if N > 20 else "nominal"]
     cs = oracle_spec(oracle, spec)
     got, st, it, kkt = _solve(gpu, spec, rec)
-    ref, st_ref, it_ref, _ = oracle.solve_batch(cs, rec)
+    ref, st_ref, it_ref, kkt_ref = oracle.solve_batch(cs, rec)
     ok_g, ok_r = np.isin(st, (0, 3)), np.isin(st_ref, (0, 3))
     # same verdict (usable: converged / acceptable, or not) on (nearly) every instance; whether a slowly
     # converging instance ends as 0 or as 3 depends on rounding (eight iterates in a row within 1e-6)
@@ -87,7 +94,7 @@ def test_parity_with_oracle(gpu, oracle, name, B, N, rate):
     # flat valley) -- checked for every one of them -- and they are few.
     out = np.where(both)[0][err >= REL_TOL]
     assert len(out) <= share * both.sum(), (len(out), int(both.sum()))
-    _explain_outliers(oracle, cs, spec, rec, got, ref, out, obj_tol=obj_tol)
+    _explain_outliers(oracle, cs, spec, rec, got, ref, out, obj_tol=obj_tol, kkt=kkt, kkt_ref=kkt_ref)
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "solver_kat_*.npz"))),
@@ -108,25 +115,35 @@ def test_independent_pins(gpu, oracle, path):
     restatement, scipy trust-constr): tests/test_independent_pins.py, tests/golden/make_independent_pins.py."""
     from test_independent_pins import check_against_pin
     pin = np.load(path)
-    spec = ProblemSpec(N=int(pin["N"]), nv=int(pin["nv"]), k1=float(pin["k1"]), k2=float(pin["k2"]), tol=1e-9, max_iter=200)
+    # (a pin is a solution to 1e-9: the solver is asked for a point of that quality -- an "acceptable" exit only within
+    # 1e-8, not at the default acceptable level 1e-4, which determines the flat directions to 1e-4 / 1e-4 = 1 only)
+    spec = ProblemSpec(N=int(pin["N"]), nv=int(pin["nv"]), k1=float(pin["k1"]), k2=float(pin["k2"]), tol=1e-9, max_iter=200,
+                       acc_tol=1e-8)
     got, st, it, kkt = _solve(gpu, spec, pin["record"][None, :])
-    assert st[0] in (0, 3) and kkt[0] < 1e-7
+    assert st[0] in (0, 3) and kkt[0] <= 1e-8
     cs = oracle_spec(oracle, spec)
     check_against_pin(pin, got[0], lambda w: oracle.evaluate(cs, pin["record"], w))
 
 
 def test_edge_cases_empty_single_and_ragged_batches(gpu, oracle):
     spec, rec = wl.make_workload("perturbed", B=67, N=10, scale=0.5)
-    ref, st_ref, _, _ = oracle.solve_batch(oracle_spec(oracle, spec), rec)
+    ref, st_ref, _, kkt_ref = oracle.solve_batch(oracle_spec(oracle, spec), rec)
     got0 = _solve(gpu, spec, rec[:0])
     assert got0[0].shape == (0, spec.nsol) and got0[1].shape == (0,)
+    cs = oracle_spec(oracle, spec)
     for B in (1, 2, 63, 65, 67):                             # around the wavefront width
-        got, st, _, _ = _solve(gpu, spec, rec[:B])
+        got, st, _, kkt = _solve(gpu, spec, rec[:B])
         ok = np.isin(st, (0, 3)) & np.isin(st_ref[:B], (0, 3))
         err = rel_inf(got[ok], ref[:B][ok])
-        # north-star tolerance for every instance; all but the occasional flat-direction instance
-        # (curvature = the 1e-4 proximal weight, KKT tolerance 1e-8) agree to rounding level
-        assert ok.mean() > 0.9 and err.max() < REL_TOL and np.median(err) < 1e-9
+        # north-star tolerance for every pair that met the tolerance on both sides; all but the occasional
+        # flat-direction instance (curvature = the 1e-4 proximal weight, KKT tolerance 1e-8) agree to rounding level; a
+        # pair with an "acceptable" member further apart than that must be the same optimum (_explain_outliers)
+        tight = (st == 0) & (st_ref[:B] == 0)
+        assert ok.mean() > 0.9 and np.median(err) < 1e-9
+        assert rel_inf(got[tight], ref[:B][tight]).max() < REL_TOL
+        far = np.where(ok)[0][err >= REL_TOL]
+        assert len(far) <= max(1, 0.03 * B)
+        _explain_outliers(oracle, cs, spec, rec[:B], got, ref[:B], far, kkt=kkt, kkt_ref=kkt_ref[:B])
 
 
 def test_batch_composition_does_not_change_results(gpu):
@@ -246,6 +263,32 @@ def test_full_size_properties_domain_randomised(gpu):
     assert r["lyapunov"].max() < 1e-5 and r["contraction"].max() < 1e-6
     assert r["swing_force"].max() < 1e-6                     # feet in the air carry nothing
     assert (kkt[st == 0] <= 100 * spec.tol).all() and (kkt[st == 3] <= spec.acc_tol).all() and (it[conv] <= spec.max_iter).all()
+
+
+def test_shipped_queue_order_is_not_worse_than_the_input_order(gpu):
+    """The queue-order predictor is a least-squares fit (csrc/cmpc_order_fit.h, tools/fit_queue_order.py) on a seed that is
+    not a BASELINE seed; it silently goes stale when the barrier schedule, the tolerance or the start changes.  Replayed
+    on the iteration counts of a real launch of the bench workload (held out from the fit), the shipped order must not
+    lose against the order the instances came in."""
+    import heapq
+    from cmpc_amd import queue_order as qo
+    spec, rec = wl.make_workload("randomized", B=8192)
+    _, st, it, _ = _solve(gpu, spec, rec)
+    slots = 256 * 6
+
+    def makespan(order):
+        h = [0] * slots
+        heapq.heapify(h)
+        end = 0
+        for i in order:
+            t = heapq.heappop(h) + int(it[i])
+            end = max(end, t)
+            heapq.heappush(h, t)
+        return end
+    shipped = np.argsort(-qo.bucket_of(qo.predicted_iterations(rec, spec)), kind="stable")
+    m_in, m_ship = makespan(np.arange(8192)), makespan(shipped)
+    assert m_ship <= m_in, (m_ship, m_in)
+    assert np.corrcoef(qo.predicted_iterations(rec, spec), it)[0, 1] > 0.4
 
 
 def test_drop_in_class_matches_reference_call_sites(gpu, oracle, scene):

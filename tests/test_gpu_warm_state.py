@@ -31,9 +31,15 @@ def test_hip_solver_resumes_like_the_oracle(oracle, N, t0, ticks):
         return out, so, st, it
 
     _, sol_g, it_g = _loop(gpu_solve, N, t0, ticks, use_state=True)
+    st_g = _loop.last_status
     _, sol_o, it_o = _loop(ora_solve, N, t0, ticks, use_state=True)
-    # (the end game of a solve is sensitive to rounding order: a step more or less here and there)
-    assert np.abs(it_g - it_o).max() <= 4 and abs(int(it_g.sum()) - int(it_o.sum())) <= max(6, 0.1 * it_o.sum()), (it_g, it_o)
+    st_o = _loop.last_status
+    # (the end game of a solve is sensitive to rounding order: a step more or less here and there.  Where one of the two
+    # ended at the acceptable level its count includes the progress watch's window of 12 iterations: iteration counts are
+    # compared on the ticks both converged on, and there must be few others)
+    tight = (st_g == 0) & (st_o == 0)
+    assert tight.sum() >= ticks - 2, (st_g, st_o)
+    assert np.abs(it_g - it_o)[tight].max() <= 4 and abs(int(it_g[tight].sum()) - int(it_o[tight].sum())) <= max(6, 0.1 * it_o[tight].sum()), (it_g, it_o)
     assert np.abs(sol_g[:, 20:26] - sol_o[:, 20:26]).max() < 1e-6          # the fed-back CoM state of every tick
     assert np.median(rel_inf(sol_g, sol_o)) < 1e-8
     assert it_g[1:].mean() < 0.7 * it_g[0]                                   # resumed ticks are cheaper than the cold first one

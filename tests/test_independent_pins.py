@@ -68,7 +68,10 @@ def test_pin_files_cover_the_walk():
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[16:-4] for f in FILES])
 def test_oracle_reproduces_independent_pins(oracle, path):
     pin = np.load(path)
-    cs = oracle.default_spec(N=int(pin["N"]), nv=int(pin["nv"]), tol=1e-9, max_iter=200, k1=float(pin["k1"]), k2=float(pin["k2"]))
+    # a pin is a solution to 1e-9: the solver is asked for that quality (an "acceptable" exit only within 1e-8; the default
+    # acceptable level 1e-4 determines the flat directions of the problem -- curvature 1e-4 -- to nothing)
+    cs = oracle.default_spec(N=int(pin["N"]), nv=int(pin["nv"]), tol=1e-9, max_iter=200, k1=float(pin["k1"]), k2=float(pin["k2"]),
+                             acc_tol=1e-8)
     sol, st, it, kkt = oracle.solve(cs, pin["record"])
-    assert st in (0, 3) and kkt < 1e-7
+    assert st in (0, 3) and kkt <= 1e-8
     check_against_pin(pin, sol, lambda w: oracle.evaluate(cs, pin["record"], w))

@@ -21,7 +21,7 @@ def _loop(solve, N, t0, ticks, use_state):
     spec, sc = ProblemSpec(N=N), wl.scene()
     com, dcom = (a[0] for a in sc.nominal_state(np.array([t0])))
     theta, warm, state = np.zeros(3), None, None
-    recs, sols, its = [], [], []
+    recs, sols, its, sts = [], [], [], []
     for t in range(t0, t0 + ticks):
         rec = sc.build_records(spec, np.array([t]), com[None], dcom[None], HW[t][None], theta[None], np.zeros(1),
                                np.zeros(1), np.full(1, wl.HRP4_MASS), np.full(1, 0.5))
@@ -30,7 +30,8 @@ def _loop(solve, N, t0, ticks, use_state):
         X = sol[0, :20 * (N + 1)].reshape(N + 1, 20)
         com, dcom, theta = X[1, 0:3].copy(), X[1, 3:6].copy(), X[1, 9:12].copy()
         warm, state = sol, state_out
-        recs.append(rec[0]); sols.append(sol[0]); its.append(int(it[0]))
+        recs.append(rec[0]); sols.append(sol[0]); its.append(int(it[0])); sts.append(int(st[0]))
+    _loop.last_status = np.array(sts)           # (per-tick outcome of the loop just run: 0 converged, 3 acceptable)
     return np.array(recs), np.array(sols), np.array(its)
 
 
@@ -101,8 +102,13 @@ def test_device_source_resumes_like_the_oracle(emu, oracle):
         return out, so, st, it
 
     _, sol_e, it_e = _loop(emu_solve, N, 255, 6, use_state=True)     # touch-down inside the horizon
+    st_e = _loop.last_status
     _, sol_o, it_o = _loop(ora_solve, N, 255, 6, use_state=True)
-    assert np.abs(it_e - it_o).max() <= 2 and abs(it_e.sum() - it_o.sum()) <= 3, (it_e, it_o)   # (end game: rounding order)
+    st_o = _loop.last_status
+    # (end game: rounding order.  Where one of the two ended at the acceptable level its count includes the progress
+    # watch's window of 12 iterations: only ticks both converged on are compared)
+    tight = (st_e == 0) & (st_o == 0)
+    assert tight.sum() >= 4 and np.abs(it_e - it_o)[tight].max() <= 2 and abs(it_e[tight].sum() - it_o[tight].sum()) <= 3, (it_e, it_o)
     assert rel_inf(sol_e, sol_o).max() < 1e-6
     assert it_e[1:].mean() < it_e[0]
 

@@ -43,13 +43,19 @@ for variant in sys.argv[1:] or [""]:
     cs = ol.default_spec(N=spec.N, nv=spec.nv, tol=spec.tol, max_iter=spec.max_iter, k1=spec.k1, k2=spec.k2, prox=spec.prox,
                          acc_tol=spec.acc_tol)
     out = np.zeros((B, ol.nsol(cs))); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kkt = np.zeros(B)
-    lib.cmpc_oracle_solve_batch(ctypes.byref(cs), B, ol._p(rec), None, ol._p(out), ol._p(st), ol._p(it), ol._p(kkt), 0)
-    itl = np.maximum(it.astype(np.int64), 1)
+    nreg = np.zeros(B, np.int32); waste = np.zeros(B)
+    lib.cmpc_oracle_solve_batch_stats(ctypes.byref(cs), B, ol._p(rec), None, ol._p(out), ol._p(st), ol._p(it), ol._p(kkt), ol._p(nreg),
+                                      ol._p(waste), 0)
+    # cost of a solve in units of 1/100 iteration: a factorisation retry repeats the matrix sweep (3/4 of an iteration) down to
+    # the failing stage; `waste` = the sweeps' worth of stages factorised in vain
+    itl = np.maximum(it.astype(np.int64), 1) * 100 + np.round(75 * waste).astype(np.int64)
     mk, bal = makespan(itl, order), itl.sum() / slots
     conv = (st == 0).mean()
     rate, val = B / mk, B / mk * conv
     base = base or (rate, val)
-    print(f"{variant or '(default)':44s} its mean {it.mean():5.2f} q90 {np.quantile(it, .9):3.0f} q99 {np.quantile(it, .99):3.0f} max {it.max():3d} | "
+    print(f"{variant or '(default)':44s} retries/solve {nreg.mean():5.2f} (= {waste.mean():4.2f} sweeps) its mean {it.mean():5.2f} q90 {np.quantile(it, .9):3.0f} q99 {np.quantile(it, .99):3.0f} max {it.max():3d} | "
           f"conv {conv:.4f} acc {(st == 3).mean():.4f} s2 {(st == 2).mean():.4f} cap {(st == 1).mean():.4f} | makespan {mk} = "
           f"{mk / bal:.3f} x balanced | all {rate / base[0]:.3f} value {val / base[1]:.3f} (relative to the first variant)"
-          f" | corr(pred, its) {np.corrcoef(pred, it)[0, 1]:.2f}", flush=True)
+          f" | corr(pred, its) {np.corrcoef(pred, it)[0, 1]:.2f}"
+          + (f" | acceptable: kkt q50 {np.quantile(kkt[st == 3], .5):.1e} q90 {np.quantile(kkt[st == 3], .9):.1e} max {kkt[st == 3].max():.1e}"
+             if (st == 3).any() else ""), flush=True)

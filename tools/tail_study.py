@@ -41,17 +41,11 @@ def makespan(order):
 
 idx = np.arange(B)
 switch_first = np.concatenate([idx[sw], idx[~sw][::-1]])          # the queue order of rounds 2-3 (switch class first)
-# the shipped order (csrc/cmpc_hip.hip, cmpc_order_bucket): decreasing predicted iteration count, 64 buckets of half an iteration
-chg = (np.diff(fl, axis=1) != 0).any(axis=2)
-first = np.where(sw, chg.argmax(axis=1), N).astype(float)
-gl0, gr0 = fl[:, 0, 0], fl[:, 0, 1]
-om = np.sqrt(spec.g / spec.cz_max)
-dcm = rec[:, 0:2] + rec[:, 3:5] / om
-both = (gl0 != 0) == (gr0 != 0)
-tgt = np.where(both[:, None], 0.5 * (rec[:, 13:15] + rec[:, 17:19]), np.where((gl0 != 0)[:, None], rec[:, 13:15], rec[:, 17:19]))
-d2 = ((dcm - tgt) ** 2).sum(axis=1)
-pred = 9.964 + 3.656 * sw + 0.158 * first + 1.916 * (gl0 + gr0) + 13.359 * np.sqrt(d2) + 170.148 * d2 + 0.075 * np.linalg.norm(rec[:, 6:9], axis=1)
-bucket = np.clip((2.0 * (pred - 10.0)).astype(int), 0, 63)
+# the shipped order (csrc/cmpc_hip.hip, cmpc_order_bucket; coefficients: csrc/cmpc_order_fit.h through cmpc_amd/queue_order.py):
+# decreasing predicted iteration count, 64 buckets of half an iteration
+from cmpc_amd import queue_order as qo
+pred = qo.predicted_iterations(rec, spec)
+bucket = qo.bucket_of(pred)
 shipped = np.argsort(-bucket, kind="stable")
 print(f"{name} B={B} N={N} nv={spec.nv}: kernel {ms:.1f} ms, slots {slots}, mean its {it.mean():.2f}, max {it.max()}, "
       f"switch class {sw.mean():.2%}")
