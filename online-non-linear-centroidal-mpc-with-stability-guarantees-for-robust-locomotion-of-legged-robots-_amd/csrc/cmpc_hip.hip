@@ -121,6 +121,31 @@ __global__ void __launch_bounds__(64 * NW, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) 
   }
 }
 
+// The pipelined pair (cmpc::Solver<4, 1, true>): two waves per instance, two LDS images + 16 exchange words.  For batches
+// that do not fill the GPU (cmpc_solve_batch picks it when B <= the pair kernel's resident grid): same results bit for
+// bit, an instance finishes ~1.4x sooner.
+template <int NV>
+__global__ void __launch_bounds__(128, 1) cmpc_solve_pair_kernel(cmpc::KArgs ka, int *ticket,
+                                                                                  const int *__restrict__ order) {
+  using D = cmpc::Dims<NV, 1>;
+  __shared__ __attribute__((aligned(16))) double lds[2 * D::LDS_DOUBLES + 16];
+  __shared__ int next;
+  double *slab = ka.scratch + (size_t)blockIdx.x * ka.scratch_stride;
+  const size_t nrec = CMPC_NREC(ka.sp.N), nsol = CMPC_NSOL(ka.sp.N, NV), nstate = CMPC_NSTATE(ka.sp.N, NV);
+  for (;;) {
+    if (threadIdx.x == 0) next = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int tk = next;
+    __syncthreads();
+    if (tk >= ka.B) break;                      // both waves reach this exit
+    const int p = __builtin_amdgcn_readfirstlane(order[__builtin_amdgcn_readfirstlane(tk)]);
+    cmpc::Solver<NV, 1, true> s(ka, lds, slab, ka.recs + (size_t)p * nrec);
+    s.solve(ka.warm ? ka.warm + (size_t)p * nsol : nullptr, ka.state_in ? ka.state_in + (size_t)p * nstate : nullptr,
+            ka.state_out ? ka.state_out + (size_t)p * nstate : nullptr, ka.out + (size_t)p * nsol, ka.status + p,
+            ka.iters + p, ka.kkt + p);
+  }
+}
+
 // One workgroup per record (grid-stride over the batch), one lane per pair of output words: each
 // lane assembles two consecutive doubles and issues one 16-byte store, so a wavefront writes 1 KiB of
 // contiguous record per instruction; reads are gathers from tables that stay L2-resident
@@ -193,6 +218,7 @@ struct cmpc_handle {
   cmpc_spec spec;
   int device = 0;
   int grid = 0;
+  int pair_grid = 0;                                // resident grid of the pipelined pair kernel (nv = 4), 0 = never used
   int num_cu = 0;
   size_t slab_doubles = 0;
   double *scratch = nullptr;
@@ -289,6 +315,17 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   }
   h->num_cu = prop.multiProcessorCount;
   h->grid = h->num_cu * resident_per_cu(spec->nv);
+  if (spec->nv == 4) {
+    // pairs a CU holds: LDS (two images) in 1280-byte granules; the pair kernel is built for one wave per SIMD (up to 512
+    // registers), i.e. at most two pairs per CU
+    const size_t granule = 1280, alloc = (sizeof(double) * (2 * cmpc::Dims<4>::LDS_DOUBLES + 16) + 16 + granule - 1) / granule * granule;
+    int n = (int)((160 * 1024) / alloc);
+    if (n > 2) n = 2;
+    h->pair_grid = h->num_cu * (n < 1 ? 1 : n);
+    if (const char *e = getenv("CMPC_PAIR")) {         // developer knob: 0 = never, 1 = always (A/B measurements)
+      if (atoi(e) == 0) h->pair_grid = 0; else h->pair_grid = 1 << 30;
+    }
+  }
   if (const char *e = getenv("CMPC_WG_PER_CU")) {      // developer knob: fewer resident workgroups per CU (occupancy studies)
     const int n = atoi(e);
     if (n >= 1 && n < resident_per_cu(spec->nv)) h->grid = h->num_cu * n;
@@ -361,7 +398,9 @@ int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, cons
   hipLaunchKernelGGL(cmpc_order_score_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->spec.N, omega, params, state_in, nstate,
                      mu_word, h->order + B, h->ticket);
   hipLaunchKernelGGL(cmpc_order_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->order + B, h->order, h->ticket);
-  if (h->spec.nv == 4)
+  if (h->spec.nv == 4 && B <= h->pair_grid)          // the batch does not fill the GPU: two waves per instance
+    hipLaunchKernelGGL((cmpc_solve_pair_kernel<4>), dim3(grid), dim3(128), 0, st, ka, h->ticket, h->order);
+  else if (h->spec.nv == 4)
     hipLaunchKernelGGL((cmpc_solve_kernel<4, 1>), dim3(grid), dim3(64), 0, st, ka, h->ticket, h->order);
   else
     hipLaunchKernelGGL((cmpc_solve_kernel<8, cmpc::WAVES_NV8>), dim3(grid), dim3(64 * cmpc::WAVES_NV8), 0, st, ka, h->ticket, h->order);

@@ -61,7 +61,17 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 #define CMPC_OPAQUE_D(x) asm volatile("" : "+v"(x))
 // the lane id again from the execution mask (two instructions): where it is re-derived the old value need not stay
 // live -- or be spilled -- across the code in front (one wave per workgroup: lane id = thread id)
-#define CMPC_RELANE(x) do { (x) = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) + 64 * wv; } while (0)
+#define CMPC_RELANE(x) do { (x) = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) + lane_base; } while (0)
+// Pipelined pair of waves (Solver<NV, 1, true>): each wave works through its own phase as a single-wave team, so inside
+// a phase a hand-off is wave-local (CMPC_SYNC_WAVE = CMPC_SYNC, CMPC_FENCE_WAVE for data that went through the slab); the
+// two waves meet at workgroup barriers only (CMPC_SYNC_WG: LDS hand-off, CMPC_SYNC_GLOBAL: global memory as well).
+#define CMPC_SYNC_WAVE(w) CMPC_SYNC()
+#define CMPC_FENCE_WAVE(w) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
+#ifdef CMPC_HOST_EMU
+#define CMPC_SYNC_WAVE(w) emu_barrier_wait(&emu_wave_barrier[(w)])
+#define CMPC_FENCE_WAVE(w) emu_barrier_wait(&emu_wave_barrier[(w)])
+#define CMPC_SYNC_WG() emu_barrier_wait(&emu_barrier)
 #endif
 #ifndef CMPC_RELANE
 #define CMPC_RELANE(x) do { } while (0)
@@ -282,14 +292,23 @@ struct GArr {
   CMPC_DEV cmpc_v2d &pair(unsigned i) const { return *(cmpc_v2d *)((char *)p + (size_t)(i * 16u)); }   // 16-byte aligned pairs
 };
 
-template <int NV, int NW = 1> struct Solver {
+// PIPE (one-wave solver only): the workgroup is a PAIR of waves on one instance.  Wave 1 evaluates stage k - 1 (loads,
+// geometry, inequality rows, Hessian rows, gradient: everything that does not need the cost-to-go of stage k) into one of
+// two LDS images while wave 0 runs the Riccati step of stage k (G'PG, factorisation, backward vectors, factor store) out
+// of the other; the cost-to-go P, its gradient and the cold scalars live in image 0 only.  Same arithmetic in the same
+// order as the single wave: results are bit for bit those of Solver<NV, 1>.  For batches that do not fill the GPU (the
+// reference's own use is ONE instance per tick, code/simulation.py:203-204): an instance finishes ~1.4x sooner.
+template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   using D = Dims<NV, NW>;
+  static_assert(!PIPE || NW == 1, "the pipelined pair runs the one-wave solver");
   static constexpr int NF = D::NF, NU = D::NU, NXA = D::NXA, NZ = D::NZ, NI = D::NI, NH = D::NH, WS = D::WS;
   static_assert(NW == 1 || NU <= 64, "the input rows (pivot chains, substitutions) live in the first wave");
 
   const KArgs &ka;
   const cmpc_spec &sp;
-  double *lds;
+  double *lds;             // LDS image the wave works on (PIPE: image k & 1 of the stage in hand)
+  double *ldsR;            // image 0: home of P, p, the cold scalars (PIPE: the Riccati wave's; otherwise = lds)
+  int lane_base = 0;       // first lane id of this wave's team (two-wave solver: 64 * wave)
   GArr gs;                 // this workgroup's scratch slab
   GArr rec;                // this instance's parameter record (read only)
   int N, lane;               // lane: 0 .. WS-1 over the workgroup (two waves: 64 * wave + lane of the wave)
@@ -304,11 +323,13 @@ template <int NV, int NW = 1> struct Solver {
   long long tprof[28] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 
   CMPC_DEV Solver(const KArgs &a, double *l, double *g, const double *r)
-      : ka(a), sp(a.sp), lds(l), gs{g}, rec{const_cast<double *>(r)}, N(a.sp.N), lane(CMPC_LANE) {
-    if constexpr (NW > 1) wv = CMPC_WAVE_ID();
+      : ka(a), sp(a.sp), lds(l), ldsR(l), gs{g}, rec{const_cast<double *>(r)}, N(a.sp.N), lane(CMPC_LANE) {
+    if constexpr (NW > 1 || PIPE) wv = CMPC_WAVE_ID();
+    if constexpr (NW > 1) lane_base = 64 * wv;
+    if constexpr (PIPE) lane &= 63;
     // (one wave per workgroup: the lane id comes from the execution mask, so that threadIdx.x need not stay live -- or be
     // spilled -- across the instance loop)
-    if constexpr (NW == 1) CMPC_RELANE(lane);
+    if constexpr (NW == 1 && !PIPE) CMPC_RELANE(lane);
     double *p = g + (size_t)(N + 1) * D::STAGE;
     gx = GArr{p}; p += (size_t)(N + 1) * NXA;
     glam = GArr{p}; p += (size_t)(N + 1) * NXA;
@@ -324,14 +345,25 @@ template <int NV, int NW = 1> struct Solver {
   }
   CMPC_DEV GArr stage(int k) const { return GArr{gs.p + (size_t)k * D::STAGE}; }
   CMPC_DEV double &L(int o) const { return lds[o]; }
+  CMPC_DEV double &R(int o) const { return ldsR[o]; }         // Riccati-owned words: P, PC, PC1, COLD
+  CMPC_DEV void image(int k) { if constexpr (PIPE) lds = ldsR + (k & 1) * D::LDS_DOUBLES; }
   // LDS hand-off between lanes: one wave needs only its own LDS traffic drained, two waves a workgroup barrier
   CMPC_DEV void sync() const {
+    if constexpr (PIPE) { CMPC_SYNC_WAVE(wv); }
+    else {
 #ifdef CMPC_HOST_EMU
-    CMPC_SYNC();
+      CMPC_SYNC();
 #else
-    if constexpr (NW == 1) CMPC_SYNC(); else CMPC_SYNC_WG();
+      if constexpr (NW == 1) CMPC_SYNC(); else CMPC_SYNC_WG();
 #endif
+    }
   }
+  // full fence for data exchanged through the slab inside a phase (PIPE: the phase belongs to one wave)
+  CMPC_DEV void gsync() const {
+    if constexpr (PIPE) { CMPC_FENCE_WAVE(wv); } else { CMPC_SYNC_GLOBAL(); }
+  }
+  // PIPE: the two waves of the pair meet (global memory included)
+  CMPC_DEV void pair_sync() const { if constexpr (PIPE) { CMPC_SYNC_GLOBAL(); } }
   CMPC_DEV bool first_wave() const { return NW == 1 || wv == 0; }
 
   // contact flag gamma_f at node k and k-1 from the staged records
@@ -901,10 +933,10 @@ template <int NV, int NW = 1> struct Solver {
               const int ia = tri(c) + q0, ib = tq0 + c;
               cmpc_lds_word pb[10];
 #pragma unroll
-              for (int q = 0; q < 10; ++q) pb[q] = cmpc_lds_word_at(&L(D::oP), (q <= t) ? ia + q : ib + offq[q]);
+              for (int q = 0; q < 10; ++q) pb[q] = cmpc_lds_word_at(&R(D::oP), (q <= t) ? ia + q : ib + offq[q]);
               lds_read_gather10(v, pb);
             } else {
-              lds_read_strided10<D::PS>(v, &L(D::oP + q0 * D::PS + cr[n]));
+              lds_read_strided10<D::PS>(v, &R(D::oP + q0 * D::PS + cr[n]));
             }
 #pragma unroll
             for (int q = 0; q < 10; ++q) acc[q] += g * v[q];
@@ -922,7 +954,7 @@ template <int NV, int NW = 1> struct Solver {
         for (int n = 0; n < 6; ++n) {
           const double g = cg[n];
           double v[QT];
-          const double *pc = &L(D::oP + q0 * D::PS + cr[n]);
+          const double *pc = &R(D::oP + q0 * D::PS + cr[n]);
           if constexpr (QT == 28) lds_read_strided28<D::PS>(v, pc);
           else if constexpr (QT == 18) lds_read_strided18<D::PS>(v, pc);
           else lds_read_strided14<D::PS>(v, pc);
@@ -1191,10 +1223,10 @@ template <int NV, int NW = 1> struct Solver {
             const bool in = (i < NXA && j <= i && mine(rb, cb));
             const double v = old[rb][cb][r] - acc[rb][cb][r];
             if constexpr (D::P_PACKED) {
-              *(in ? &L(D::oP + tri(i) + j) : dump) = v;
+              *(in ? &R(D::oP + tri(i) + j) : dump) = v;
             } else {
-              *(in ? &L(D::oP + i * D::PS + j) : dump) = v;
-              *(in ? &L(D::oP + j * D::PS + i) : dump) = v;
+              *(in ? &R(D::oP + i * D::PS + j) : dump) = v;
+              *(in ? &R(D::oP + j * D::PS + i) : dump) = v;
             }
             *pm[rb][cb][r] = v;                 // and into the packed image the factor store copies out
           }
@@ -1270,7 +1302,7 @@ template <int NV, int NW = 1> struct Solver {
 #pragma unroll
       for (int n = 0; n < 6; ++n) {
         a0 += lg[h][n] * L(D::oXN1 + lr[h][n]);
-        a1 += lg[h][n] * L(D::oPC1 + lr[h][n]);
+        a1 += lg[h][n] * R(D::oPC1 + lr[h][n]);
       }
       L(D::oTV + col) = a0; L(D::oAL + col) = a1;
     }
@@ -1331,7 +1363,7 @@ template <int NV, int NW = 1> struct Solver {
       }
       if (lane < NXA) {
         const double p0 = L(D::oTV + NU + lane) - (a0 + a1), p1 = L(D::oAL + NU + lane) - (b0 + b1);
-        L(D::oPC + lane) = p0; L(D::oPC1 + lane) = p1;
+        R(D::oPC + lane) = p0; R(D::oPC1 + lane) = p1;
         st[D::gPV + lane] = p0; st[D::gPV1 + lane] = p1;
       }
     }
@@ -1339,6 +1371,164 @@ template <int NV, int NW = 1> struct Solver {
   }
 
   struct Err { double e_d, e_p, e_c, e_cmu, sum_mult; int n_mult; };
+
+  // One stage of the matrix sweep in two halves.  eval_stage: everything that does not need the cost-to-go of stage k + 1
+  // (loads, geometry, inequality rows, barrier weights, Hessian rows, gradient; KKT error measures).  riccati_stage: the
+  // part that does (P b, G'PG, factorisation, backward vectors, factor store); false on wrong inertia.  A single wave runs
+  // them back to back; the pipelined pair runs eval_stage(k - 1) beside riccati_stage(k) on two LDS images.
+  CMPC_DEV void eval_stage(int k, double mu, double reg, double wz, double x0n2, Err &er, bool init) {
+    CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+    load_stage(k);
+    CMPC_TICK(24);
+    if (k < N) {
+      stage_geometry(k);
+    } else {
+      for (int c = lane; c < 3 * NZ; c += WS) L(D::oGH + c) = 0.0;
+      if (lane < NXA) L(D::oBV + lane) = 0.0;
+      sync();
+    }
+    CMPC_TICK(11);
+    stage_ineq(k, x0n2);
+    CMPC_TICK(12);
+    // barrier weights (W2 holds the activity flag on entry); on the very first sweep the slacks and
+    // multipliers are created here: s = max(-g, 1e-2), z = mu / s
+    for (int r = lane; r < NI; r += WS) {
+      const bool act = L(D::oW2 + r) != 0.0;
+      const double g = L(D::oGK + r);
+      double s = L(D::oSK + r), z = L(D::oZK + r);
+      if (init) {
+        // rows carried over from the solver state; the cold rule for the rest (also: rows a contact switch has
+        // just activated)
+        // (initial_point left the state's slacks and multipliers in the iterate arrays, zeros on a cold start)
+        const bool carry = act && s > 0.0 && z > 0.0;
+        s = carry ? s : (act ? fmax(-g, fmin(1e-2, sqrt(mu))) : 1.0);
+        z = carry ? z : (act ? mu / s : 0.0);
+        L(D::oZK + r) = z;
+        gsl[k * NI + r] = s; gz[k * NI + r] = z;
+      }
+      if (act) {
+        const double sg = z / s;
+        L(D::oW0 + r) = sg; L(D::oW1 + r) = sg * (g + s); L(D::oW2 + r) = 1.0 / s;
+        er.e_p = fmax(er.e_p, fabs(g + s));
+        er.e_c = fmax(er.e_c, fabs(s * z)); er.e_cmu = fmax(er.e_cmu, fabs(s * z - mu));
+        er.sum_mult += fabs(z); er.n_mult += 1;
+      } else {
+        L(D::oW0 + r) = 0.0; L(D::oW1 + r) = 0.0; L(D::oW2 + r) = 0.0; L(D::oZK + r) = 0.0;
+      }
+    }
+    if (k < N && lane < NXA) er.e_p = fmax(er.e_p, fabs(L(D::oBV + lane)));
+    if (k >= 1 && lane < NXA) { er.sum_mult += fabs(L(D::oLAMK + lane)); er.n_mult += 1; }
+    sync();
+    CMPC_TICK(25);
+    // Hessian rows first: the column lists of [B A] (18 registers per lane) are not live across them
+    CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+    build_H(k, reg, wz);
+    CMPC_TICK(1);
+    CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+    build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
+    const GArr st = stage(k);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int col = lane + WS * h;
+      if (col >= NZ) continue;
+      const double ho = cost_grad(k, col, wz);
+      double jw[3];
+      jgt3(k, col, jw);
+      double r = ho + jw[0];
+      if (k < N) for (int n = 0; n < 6; ++n) r += lg[h][n] * L(D::oLAMN + lr[h][n]);
+      if (col >= NU) r -= L(D::oLAMK + col - NU);
+      const bool is_var = (col < NU) ? (k < N) : (k >= 1);
+      if (is_var) er.e_d = fmax(er.e_d, fabs(r));
+      L(D::oH0 + col) = ho + jw[1] + mu * jw[2];   // gradient at the sweep's barrier value (see backward_vectors)
+      L(D::oH1 + col) = jw[2];
+      st[D::gAL + col] = L(D::oAL + col);
+    }
+    CMPC_TICK(26);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int c = lane + WS * h;
+      if (c < NZ) { st[D::gGH + c] = L(D::oGH + c); st[D::gGH + D::GHS + c] = L(D::oGH + NZ + c); st[D::gGH + 2 * D::GHS + c] = L(D::oGH + 2 * NZ + c); }
+    }
+    for (int r = lane; r < NI; r += WS) st[D::gG + r] = L(D::oGK + r);
+    CMPC_TICK(0);
+    sync();
+  }
+  CMPC_DEV bool riccati_stage(int k) {
+    const GArr st = stage(k);
+    if constexpr (PIPE) {                      // (the evaluating wave built its own copy of the column lists)
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+      build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
+    }
+    if (k < N) {
+      // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG
+      if (lane < NXA) {
+        const double *bv = &L(D::oBV);
+        double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        if constexpr (D::P_PACKED) {
+          // row `lane` of the packed triangle: columns <= lane contiguous in the row, the others down column `lane`
+          static_assert(!D::P_PACKED || NXA == 28, "three batches of ten");
+          double pr[30];
+          {
+            const int tl = tri(lane);
+#pragma unroll
+            for (int q0 = 0; q0 < 30; q0 += 10) {
+              cmpc_lds_word pa[10];
+              double v[10];
+#pragma unroll
+              for (int q = 0; q < 10; ++q) {
+                const int qq = (q0 + q < NXA) ? q0 + q : NXA - 1;          // (the last batch repeats column 27 twice)
+                pa[q] = cmpc_lds_word_at(&R(D::oP), (qq <= lane) ? tl + qq : tri(qq) + lane);
+              }
+              lds_read_gather10(v, pa);
+#pragma unroll
+              for (int q = 0; q < 10; ++q) pr[q0 + q] = v[q];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < NXA; q += 4) {
+            b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
+          }
+        } else {
+        const double *pr = &R(D::oP + lane * D::PS);
+#pragma unroll
+        for (int q = 0; q < NXA; q += 4) {
+          b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
+        }
+        }
+        const double a = (b0 + b1) + (b2 + b3);
+        L(D::oXN1 + lane) = R(D::oPC + lane) + a;       // v0 = p0_{k+1} + P_{k+1} b
+        st[D::gB + lane] = L(D::oBV + lane);
+      }
+      sync();                            // the T tile of add_GtPG aliases BV and the other stage vectors
+      CMPC_TICK(13);
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+      add_GtPG(L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
+      CMPC_TICK(14);
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+      if (!factor_stage(k)) return false;
+      CMPC_TICK(8);
+      backward_vectors(k);
+      CMPC_TICK(5);
+    } else {
+      if (lane < NXA) {                      // terminal cost-to-go gradient p_N = h_N (x part), split in mu
+        const double p0 = L(D::oH0 + NU + lane), p1 = L(D::oH1 + NU + lane);
+        R(D::oPC + lane) = p0; R(D::oPC1 + lane) = p1;
+        st[D::gPV + lane] = p0; st[D::gPV1 + lane] = p1;
+      }
+      for (int e = lane; e < NXA * NXA; e += WS) {
+        const int i = e / NXA, c = e % NXA;
+        const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
+        if constexpr (D::P_PACKED) { if (c <= i) R(D::oP + tri(i) + c) = L(D::oM + tri(NU + i) + NU + c); }
+        else R(D::oP + i * D::PS + c) = L(D::oM + tri(NU + hi) + NU + lo);
+      }
+      sync();
+    }
+    CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+    store_factors(k);
+    sync();
+    CMPC_TICK(4);
+    return true;
+  }
 
   // ---------------------------------------------------------------------------------------
   // Matrix sweep: evaluate + factorise every stage backwards.  Returns false on wrong inertia.
@@ -1351,154 +1541,40 @@ template <int NV, int NW = 1> struct Solver {
     // e^{-(k-1)} by repeated multiplication as k runs down (the library exp is ~1.5 KB of code per use)
     const double e1 = 2.718281828459045235360287;
     double ez = exp(-(double)(N - 1));
-    for (int k = N; k >= 0; --k) {
-      const double wz = sp.w_cz_const * 0.5 * ez + sp.w_cz_const * 0.5;
-      ez *= e1;
-      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-      load_stage(k);
-      CMPC_TICK(24);
-      if (k < N) {
-        stage_geometry(k);
-      } else {
-        for (int c = lane; c < 3 * NZ; c += WS) L(D::oGH + c) = 0.0;
-        if (lane < NXA) L(D::oBV + lane) = 0.0;
-        sync();
+    if constexpr (!PIPE) {
+      for (int k = N; k >= 0; --k) {
+        const double wz = sp.w_cz_const * 0.5 * ez + sp.w_cz_const * 0.5;
+        ez *= e1;
+        eval_stage(k, mu, reg, wz, x0n2, er, init);
+        if (!riccati_stage(k)) return false;
       }
-      CMPC_TICK(11);
-      stage_ineq(k, x0n2);
-      CMPC_TICK(12);
-      // barrier weights (W2 holds the activity flag on entry); on the very first sweep the slacks and
-      // multipliers are created here: s = max(-g, 1e-2), z = mu / s
-      for (int r = lane; r < NI; r += WS) {
-        const bool act = L(D::oW2 + r) != 0.0;
-        const double g = L(D::oGK + r);
-        double s = L(D::oSK + r), z = L(D::oZK + r);
-        if (init) {
-          // rows carried over from the solver state; the cold rule for the rest (also: rows a contact switch has
-          // just activated)
-          // (initial_point left the state's slacks and multipliers in the iterate arrays, zeros on a cold start)
-          const bool carry = act && s > 0.0 && z > 0.0;
-          s = carry ? s : (act ? fmax(-g, fmin(1e-2, sqrt(mu))) : 1.0);
-          z = carry ? z : (act ? mu / s : 0.0);
-          L(D::oZK + r) = z;
-          gsl[k * NI + r] = s; gz[k * NI + r] = z;
+      return true;
+    } else {
+      // step j: wave 1 evaluates stage N - j into image (N - j) & 1 while wave 0 takes stage N - j + 1 out of the other
+      // image; one workgroup barrier per step.  A failed factorisation is published in the exchange words behind the
+      // two images and seen by both waves after the barrier of its step.
+      // (the verdict of step j sits in word 8 + (j & 1): wave 0 may be a step ahead of wave 1's read of the last one)
+      double *xch = ldsR + 2 * D::LDS_DOUBLES;
+      if (lane == 0 && wv == 0) { xch[8] = 0.0; xch[9] = 0.0; }
+      CMPC_SYNC_WG();
+      for (int j = 0; j <= N + 1; ++j) {
+        if (wv == 1) {
+          const int k = N - j;
+          const double wz = sp.w_cz_const * 0.5 * ez + sp.w_cz_const * 0.5;
+          ez *= e1;
+          if (k >= 0) { image(k); eval_stage(k, mu, reg, wz, x0n2, er, init); }
+        } else if (j >= 1) {
+          const int k = N - j + 1;
+          image(k);
+          if (!riccati_stage(k) && lane == 0) xch[8 + (j & 1)] = 1.0;
         }
-        if (act) {
-          const double sg = z / s;
-          L(D::oW0 + r) = sg; L(D::oW1 + r) = sg * (g + s); L(D::oW2 + r) = 1.0 / s;
-          er.e_p = fmax(er.e_p, fabs(g + s));
-          er.e_c = fmax(er.e_c, fabs(s * z)); er.e_cmu = fmax(er.e_cmu, fabs(s * z - mu));
-          er.sum_mult += fabs(z); er.n_mult += 1;
-        } else {
-          L(D::oW0 + r) = 0.0; L(D::oW1 + r) = 0.0; L(D::oW2 + r) = 0.0; L(D::oZK + r) = 0.0;
-        }
+        CMPC_SYNC_WG();
+        const bool failed = xch[8 + (j & 1)] != 0.0;
+        if (failed) { image(0); CMPC_SYNC_WG(); return false; }
       }
-      if (k < N && lane < NXA) er.e_p = fmax(er.e_p, fabs(L(D::oBV + lane)));
-      if (k >= 1 && lane < NXA) { er.sum_mult += fabs(L(D::oLAMK + lane)); er.n_mult += 1; }
-      sync();
-      CMPC_TICK(25);
-      // Hessian rows first: the column lists of [B A] (18 registers per lane) are not live across them
-      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-      build_H(k, reg, wz);
-      CMPC_TICK(1);
-      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-      build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
-      const GArr st = stage(k);
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int col = lane + WS * h;
-        if (col >= NZ) continue;
-        const double ho = cost_grad(k, col, wz);
-        double jw[3];
-        jgt3(k, col, jw);
-        double r = ho + jw[0];
-        if (k < N) for (int n = 0; n < 6; ++n) r += lg[h][n] * L(D::oLAMN + lr[h][n]);
-        if (col >= NU) r -= L(D::oLAMK + col - NU);
-        const bool is_var = (col < NU) ? (k < N) : (k >= 1);
-        if (is_var) er.e_d = fmax(er.e_d, fabs(r));
-        L(D::oH0 + col) = ho + jw[1] + mu * jw[2];   // gradient at the sweep's barrier value (see backward_vectors)
-        L(D::oH1 + col) = jw[2];
-        st[D::gAL + col] = L(D::oAL + col);
-      }
-      CMPC_TICK(26);
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int c = lane + WS * h;
-        if (c < NZ) { st[D::gGH + c] = L(D::oGH + c); st[D::gGH + D::GHS + c] = L(D::oGH + NZ + c); st[D::gGH + 2 * D::GHS + c] = L(D::oGH + 2 * NZ + c); }
-      }
-      for (int r = lane; r < NI; r += WS) st[D::gG + r] = L(D::oGK + r);
-      CMPC_TICK(0);
-      sync();
-      if (k < N) {
-        // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG
-        if (lane < NXA) {
-          const double *bv = &L(D::oBV);
-          double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-          if constexpr (D::P_PACKED) {
-            // row `lane` of the packed triangle: columns <= lane contiguous in the row, the others down column `lane`
-            static_assert(!D::P_PACKED || NXA == 28, "three batches of ten");
-            double pr[30];
-            {
-              const int tl = tri(lane);
-#pragma unroll
-              for (int q0 = 0; q0 < 30; q0 += 10) {
-                cmpc_lds_word pa[10];
-                double v[10];
-#pragma unroll
-                for (int q = 0; q < 10; ++q) {
-                  const int qq = (q0 + q < NXA) ? q0 + q : NXA - 1;          // (the last batch repeats column 27 twice)
-                  pa[q] = cmpc_lds_word_at(&L(D::oP), (qq <= lane) ? tl + qq : tri(qq) + lane);
-                }
-                lds_read_gather10(v, pa);
-#pragma unroll
-                for (int q = 0; q < 10; ++q) pr[q0 + q] = v[q];
-              }
-            }
-#pragma unroll
-            for (int q = 0; q < NXA; q += 4) {
-              b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
-            }
-          } else {
-          const double *pr = &L(D::oP + lane * D::PS);
-#pragma unroll
-          for (int q = 0; q < NXA; q += 4) {
-            b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
-          }
-          }
-          const double a = (b0 + b1) + (b2 + b3);
-          L(D::oXN1 + lane) = L(D::oPC + lane) + a;       // v0 = p0_{k+1} + P_{k+1} b
-          st[D::gB + lane] = L(D::oBV + lane);
-        }
-        sync();                            // the T tile of add_GtPG aliases BV and the other stage vectors
-        CMPC_TICK(13);
-        CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-        add_GtPG(L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
-        CMPC_TICK(14);
-        CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-        if (!factor_stage(k)) return false;
-        CMPC_TICK(8);
-        backward_vectors(k);
-        CMPC_TICK(5);
-      } else {
-        if (lane < NXA) {                      // terminal cost-to-go gradient p_N = h_N (x part), split in mu
-          const double p0 = L(D::oH0 + NU + lane), p1 = L(D::oH1 + NU + lane);
-          L(D::oPC + lane) = p0; L(D::oPC1 + lane) = p1;
-          st[D::gPV + lane] = p0; st[D::gPV1 + lane] = p1;
-        }
-        for (int e = lane; e < NXA * NXA; e += WS) {
-          const int i = e / NXA, c = e % NXA;
-          const int hi = (i > c) ? i : c, lo = (i > c) ? c : i;
-          if constexpr (D::P_PACKED) { if (c <= i) L(D::oP + tri(i) + c) = L(D::oM + tri(NU + i) + NU + c); }
-          else L(D::oP + i * D::PS + c) = L(D::oM + tri(NU + hi) + NU + lo);
-        }
-        sync();
-      }
-      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-      store_factors(k);
-      sync();
-      CMPC_TICK(4);
+      image(0);
+      return true;
     }
-    return true;
   }
 
   // reductions over the instance's lanes: six butterfly steps inside a wave, no LDS; with two waves the
@@ -1506,9 +1582,9 @@ template <int NV, int NW = 1> struct Solver {
   enum { OP_MAX = 0, OP_MIN = 1, OP_SUM = 2 };
   CMPC_DEV double across_waves(double v, int op) {
     if constexpr (NW == 1) return v;
-    if ((lane & 63) == 0) L(D::oCOLD + 4 + wv) = v;
+    if ((lane & 63) == 0) R(D::oCOLD + 4 + wv) = v;
     sync();
-    const double a = L(D::oCOLD + 4), b = L(D::oCOLD + 5);
+    const double a = R(D::oCOLD + 4), b = R(D::oCOLD + 5);
     sync();
     return (op == OP_MAX) ? fmax(a, b) : (op == OP_MIN) ? fmin(a, b) : a + b;
   }
@@ -1544,7 +1620,7 @@ template <int NV, int NW = 1> struct Solver {
     const bool isA = lane < NU;
     const int lb = MERGE ? lane - NU : lane;
     const bool isB = lb >= 0 && lb < NXA;
-    CMPC_SYNC_GLOBAL();                       // the slab was written with another lane mapping
+    gsync();                                  // the slab was written with another lane mapping
     int cur = D::oXK, nxt = D::oXN1;          // dx_k / dx_{k+1} ping-pong
     if (lane < NXA) { L(cur + lane) = 0.0; gdx[lane] = 0.0; }
     sync();
@@ -1675,12 +1751,12 @@ template <int NV, int NW = 1> struct Solver {
           s0 += CMPC_XOR(s0, mm); s1 += CMPC_XOR(s1, mm); s2 += CMPC_XOR(s2, mm); s3 += CMPC_XOR(s3, mm);
         }
         if ((lane & 63) == 0) {
-          double *w = &L(wv == 0 ? D::oRED : D::oCOLD + 4);
+          double *w = (wv == 0) ? &L(D::oRED) : &R(D::oCOLD + 4);
           w[0] = s0; w[1] = s1; w[2] = s2; w[3] = s3;
         }
         sync();
-        s0 = L(D::oRED) + L(D::oCOLD + 4); s1 = L(D::oRED + 1) + L(D::oCOLD + 5);
-        s2 = L(D::oRED + 2) + L(D::oCOLD + 6); s3 = L(D::oRED + 3) + L(D::oCOLD + 7);
+        s0 = L(D::oRED) + R(D::oCOLD + 4); s1 = L(D::oRED + 1) + R(D::oCOLD + 5);
+        s2 = L(D::oRED + 2) + R(D::oCOLD + 6); s3 = L(D::oRED + 3) + R(D::oCOLD + 7);
       }
       sync();
       slack_dirs(s3);
@@ -1734,7 +1810,7 @@ template <int NV, int NW = 1> struct Solver {
   }
 
   CMPC_DEV void apply_step(double mu, double ap, double ad) {
-    CMPC_SYNC_GLOBAL();                       // directions were written with a per-stage lane mapping
+    gsync();                                  // directions were written with a per-stage lane mapping
     // elementwise updates, four independent load groups in flight per pass
     constexpr int UF = 4;
     for (int e0 = NXA; e0 < (N + 1) * NXA; e0 += WS * UF) {
@@ -1781,7 +1857,7 @@ template <int NV, int NW = 1> struct Solver {
         }
       }
     }
-    CMPC_SYNC_GLOBAL();
+    gsync();
   }
 
   // Initial point: warm start or hover forces; x_0 from the record; carried f_z states.
@@ -1828,12 +1904,12 @@ template <int NV, int NW = 1> struct Solver {
       gsl[e] = resume ? st_in[D::state_s(N) + ks * NI + i] : 0.0;
       gz[e] = resume ? st_in[D::state_z(N) + ks * NI + i] : 0.0;
     }
-    CMPC_SYNC_GLOBAL();
+    gsync();
     for (int e = lane; e < N * NF; e += WS) {
       const int k = e / NF + 1, j = e % NF;
       gx[k * NXA + CMPC_NX + j] = gu[(k - 1) * NU + 3 * j + 2];
     }
-    CMPC_SYNC_GLOBAL();
+    gsync();
     if (COLD_ROLLOUT && !has_warm) {
       // dynamics-consistent cold start (see the oracle): x_{k+1} = F(x_k, u_k) under the initial inputs.  The stage loader
       // and the geometry phase do the evaluation: with x_{k+1} zeroed in LDS the defect b = F(x, u) - x_{k+1} IS F(x, u).
@@ -1843,7 +1919,7 @@ template <int NV, int NW = 1> struct Solver {
         sync();
         stage_geometry(k);
         if (lane < NXA) gx[(k + 1) * NXA + lane] = L(D::oBV + lane);
-        CMPC_SYNC_GLOBAL();
+        gsync();
       }
     }
   }
@@ -1859,7 +1935,7 @@ template <int NV, int NW = 1> struct Solver {
   // Solver state for the next tick (CMPC_NSTATE, include/cmpc.h): the current iterate, labelled with its barrier value.
   CMPC_DEV void write_state(double *state_out, double mu_level) {
     const GArr so{state_out};
-    CMPC_SYNC_GLOBAL();                         // (first iteration: the slacks were written by the sweep's lane mapping)
+    gsync();                                    // (first iteration: the slacks were written by the sweep's lane mapping)
     write_solution(state_out);
     for (int e = lane; e < (N + 1) * NXA; e += WS) so[D::state_lam(N) + e] = glam[e];
     for (int e = lane; e < (N + 1) * NI; e += WS) { so[D::state_s(N) + e] = gsl[e]; so[D::state_z(N) + e] = gz[e]; }
@@ -1896,8 +1972,8 @@ template <int NV, int NW = 1> struct Solver {
     bool use_saved = false;
     // cold scalars of the outer loop live in LDS (every lane reads the same word; written by every lane with the
     // same value, fenced by the phases in between)
-    double &reg_last = L(D::oCOLD + 0), &kkt_best = L(D::oCOLD + 1), &kkt_saved = L(D::oCOLD + 2);
-    double &snapped = L(D::oCOLD + 3);          // 1 once the solver state of this solve has been written
+    double &reg_last = R(D::oCOLD + 0), &kkt_best = R(D::oCOLD + 1), &kkt_saved = R(D::oCOLD + 2);
+    double &snapped = R(D::oCOLD + 3);          // 1 once the solver state of this solve has been written
     {
       double inf = INFINITY, zero = 0.0;        // (materialised here: hoisted out of the instance loop they were spilled)
       CMPC_OPAQUE_D(inf); CMPC_OPAQUE_D(zero);
@@ -1910,7 +1986,9 @@ template <int NV, int NW = 1> struct Solver {
     auto acc_raw = [&]() { double a = sp.acc_tol; CMPC_OPAQUE_D(a); return a; };
     auto acc_tol = [&]() { return fmax(acc_raw(), tol); };
     auto save_tol = [&]() { return fmax(fmax(acc_raw(), tol), ACC_FACTOR * tol); };
-    initial_point(resume ? state_in : warm, warm, resume);
+    // (the pair: phases that walk the horizon serially belong to wave 0; the other wave waits at the next barrier)
+    if (!PIPE || wv == 0) initial_point(resume ? state_in : warm, warm, resume);
+    pair_sync();
     CMPC_TICK_RESET();
     for (it = 0; it <= sp.max_iter - spent; ++it) {
       double reg = 0.0;
@@ -1925,8 +2003,16 @@ template <int NV, int NW = 1> struct Solver {
         if (reg > 1e20) { fail = true; break; }
       }
       if (fail) { st = CMPC_NUMERICAL; break; }
-      const double e_d = red_max(er.e_d), e_p = red_max(er.e_p), e_c = red_max(er.e_c), e_cmu = red_max(er.e_cmu);
-      const double sm = red_sum(er.sum_mult), nm = red_sum((double)er.n_mult);
+      double e_d = red_max(er.e_d), e_p = red_max(er.e_p), e_c = red_max(er.e_c), e_cmu = red_max(er.e_cmu);
+      double sm = red_sum(er.sum_mult), nm = red_sum((double)er.n_mult);
+      if constexpr (PIPE) {
+        // the error measures were gathered by the evaluating wave: handed to both through the exchange words; the same
+        // barrier orders the slab writes of the sweep (both waves') before the vector sweep of wave 0
+        double *xch = ldsR + 2 * D::LDS_DOUBLES;
+        if (wv == 1 && lane == 0) { xch[0] = e_d; xch[1] = e_p; xch[2] = e_c; xch[3] = e_cmu; xch[4] = sm; xch[5] = nm; }
+        pair_sync();
+        e_d = xch[0]; e_p = xch[1]; e_c = xch[2]; e_cmu = xch[3]; sm = xch[4]; nm = xch[5];
+      }
       const double sd = fmax(100.0, sm / fmax(nm, 1.0)) / 100.0;
       kkt = fmax(fmax(e_d / sd, e_p), e_c / sd);
 #ifdef CMPC_HOST_EMU
@@ -1935,7 +2021,8 @@ template <int NV, int NW = 1> struct Solver {
 #endif
       const double ebar = fmax(fmax(e_d / sd, e_p), e_cmu / sd);   // error of the barrier problem at mu
       double ks = kkt_saved, kb = kkt_best;     // cold state: every lane reads before any lane writes
-      sync();
+      const bool unsnapped = snapped == 0.0;
+      if constexpr (PIPE) { CMPC_SYNC_WG(); } else sync();
       if (polish >= 0 && kkt > ACC_FACTOR * tol) {
         // polishing lost ground (the step at the final barrier value needed an inertia correction): the point
         // that met the tolerance was written to `out` before the polish and is what is returned
@@ -1943,10 +2030,10 @@ template <int NV, int NW = 1> struct Solver {
       }
       if (polish < 0) {
         // best acceptable iterate so far (see the oracle): whatever ends the run, it is what is returned
-        if (kkt <= save_tol() && kkt < ks) { write_solution(out); ks = kkt; kkt_saved = kkt; }
+        if (kkt <= save_tol() && kkt < ks) { if (!PIPE || wv == 0) write_solution(out); ks = kkt; kkt_saved = kkt; }
         if (kkt <= tol) {
           // (the tolerance was met from a level >= MU_WARM: same snapshot)
-          if (state_out && mu >= MU_WARM && snapped == 0.0) { write_state(state_out, mu); snapped = 1.0; }
+          if (state_out && mu >= MU_WARM && unsnapped) { if (!PIPE || wv == 0) write_state(state_out, mu); snapped = 1.0; }
           polish = POLISH_ITERS; mu = tol / 10;
         } else {
           n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
@@ -1984,22 +2071,36 @@ template <int NV, int NW = 1> struct Solver {
           kkt_best = inf; since_best = 0;
         }
         // this iterate solves the barrier problem at mu_before: the state the next tick resumes from
-        if (state_out && mu_before >= MU_WARM && mu < MU_WARM && snapped == 0.0) { write_state(state_out, mu_before); snapped = 1.0; }
+        if (state_out && mu_before >= MU_WARM && mu < MU_WARM && unsnapped) { if (!PIPE || wv == 0) write_state(state_out, mu_before); snapped = 1.0; }
       }
       double ap, ad;
-      vector_sweeps(mu, mu - mu_sweep, ap, ad);
-      CMPC_TICK(6);
-      n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
-      apply_step(mu, ap, ad);
-      CMPC_TICK(7);
+      if constexpr (PIPE) {
+        double *xch = ldsR + 2 * D::LDS_DOUBLES;
+        if (wv == 0) {
+          vector_sweeps(mu, mu - mu_sweep, ap, ad);
+          CMPC_TICK(6);
+          apply_step(mu, ap, ad);
+          CMPC_TICK(7);
+          if (lane == 0) xch[6] = ap;
+        }
+        pair_sync();                            // the new iterate (global) and the step length reach the other wave
+        ap = xch[6];
+        n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
+      } else {
+        vector_sweeps(mu, mu - mu_sweep, ap, ad);
+        CMPC_TICK(6);
+        n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
+        apply_step(mu, ap, ad);
+        CMPC_TICK(7);
+      }
     }
-    if (!use_saved) write_solution(out);
+    if (!use_saved && (!PIPE || wv == 0)) write_solution(out);
     if (!(resume && (st == CMPC_MAX_ITER || st == CMPC_NUMERICAL))) break;
     if (it >= sp.max_iter) break;               // nothing left of the budget
     spent += it; resume = false;
-    CMPC_SYNC_GLOBAL();
+    if constexpr (PIPE) pair_sync(); else gsync();
     }
-    if (lane == 0) {
+    if (lane == 0 && (!PIPE || wv == 0)) {
       *status = st; *iters = it + spent; *kkt_out = kkt;
       // (first spare word of the state: what this solve took -- the next launch queues its instances by it)
       if (state_out) GArr{state_out}[D::state_mu(N) + 1] = (double)(it + spent);
@@ -2008,7 +2109,7 @@ template <int NV, int NW = 1> struct Solver {
     if (lane == 0 && ka.prof)
       for (int i = 0; i < 28; ++i) atomicAdd((unsigned long long *)&ka.prof[i], (unsigned long long)tprof[i]);
 #endif
-    sync();
+    if constexpr (PIPE) pair_sync(); else sync();
   }
 };
 

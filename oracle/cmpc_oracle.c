@@ -732,6 +732,7 @@ static void solve_one_capped(const cmpc_spec *sp, const double *rec, const doubl
    * counter could otherwise end the run with nothing in `out` */
   const double save_tol = fmax(acc_tol, ACC_FACTOR * tol);
   double dbg_ap = 0, dbg_ad = 0;
+  int dbg_bk = -1, dbg_bi = -1;       /* row that limited the last primal step (verbose trace) */
   double kkt = INFINITY;
   double *xn = (double *)malloc(sizeof(double) * nx);
   for (it = 0; it <= cap; ++it) {
@@ -774,7 +775,7 @@ static void solve_one_capped(const cmpc_spec *sp, const double *rec, const doubl
     double sd = fmax(100.0, sum_mult / n_mult) / 100.0;
     kkt = fmax(fmax(e_d / sd, e_p), e_c / sd);
     if (verbose)
-      printf("it %3d f=%.8e d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e  (last step: ap %.3f ad %.3f; largest dual residual: stage %d column %d)\n", it, fobj, e_d / sd, e_p, e_c / sd, mu, reg_last, dbg_ap, dbg_ad, dbg_k, dbg_j);
+      printf("it %3d f=%.8e d=%.2e p=%.2e c=%.2e mu=%.1e reg=%.1e  (last step: ap %.3f ad %.3f, limited by row %d of stage %d; largest dual residual: stage %d column %d)\n", it, fobj, e_d / sd, e_p, e_c / sd, mu, reg_last, dbg_ap, dbg_ad, dbg_bi, dbg_bk, dbg_k, dbg_j);
     if (polish >= 0 && kkt > ACC_FACTOR * tol) {
       /* polishing lost ground (the step at the final barrier value needed an inertia correction): the
        * point that met the tolerance was written to `out` before the polish and is what is returned */
@@ -891,6 +892,7 @@ static void solve_one_capped(const cmpc_spec *sp, const double *rec, const doubl
           for (int p = 0; p < nx; ++p) jd += Jg[(size_t)i * nz + nu + p] * W->dx[(size_t)k * nx + p];
           ds = -(g[i] + s[i]) - jd;
           dz = (mu - s[i] * z[i] - z[i] * ds) / s[i];
+          if (ds < 0 && -tau * s[i] / ds < ap) { dbg_bk = k; dbg_bi = i; }
           if (ds < 0) ap = fmin(ap, -tau * s[i] / ds);
           if (dz < 0) ad = fmin(ad, -tau * z[i] / dz);
         }

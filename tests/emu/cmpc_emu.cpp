@@ -82,16 +82,16 @@ static inline cmpc_v4d emu_mfma(double a, double b, cmpc_v4d c) {
 
 #include "../../online-non-linear-centroidal-mpc-with-stability-guarantees-for-robust-locomotion-of-legged-robots-_amd/csrc/cmpc_kernel.hpp"
 
-template <int NV, int NW>
+template <int NV, int NW, bool PIPE = false>
 static void run_batch(const cmpc::KArgs &ka, double *lds) {
   const cmpc_spec &sp = ka.sp;
   const size_t nrec = CMPC_NREC(sp.N), nsol = CMPC_NSOL(sp.N, NV), nstate = CMPC_NSTATE(sp.N, NV);
   for (int p = 0; p < ka.B; ++p) {
     std::vector<std::thread> th;
-    for (int l = 0; l < 64 * NW; ++l)
+    for (int l = 0; l < 64 * (PIPE ? 2 : NW); ++l)
       th.emplace_back([&, l]() {
         emu_lane_id = l;
-        cmpc::Solver<NV, NW> s(ka, lds, ka.scratch, ka.recs + p * nrec);
+        cmpc::Solver<NV, NW, PIPE> s(ka, lds, ka.scratch, ka.recs + p * nrec);
         s.solve(ka.warm ? ka.warm + p * nsol : nullptr, ka.state_in ? ka.state_in + p * nstate : nullptr,
                 ka.state_out ? ka.state_out + p * nstate : nullptr, ka.out + p * nsol, ka.status + p, ka.iters + p, ka.kkt + p);
       });
@@ -119,15 +119,18 @@ extern "C" int cmpc_emu_solve_batch_state(const cmpc_spec *sp, int32_t B, const 
   if (nw8 != 1 && nw8 != 2) return 1;
   const size_t nd = (sp->nv == 4) ? cmpc::Dims<4>::scratch_doubles(sp->N)
                     : (nw8 == 2)  ? cmpc::Dims<8, 2>::scratch_doubles(sp->N) : cmpc::Dims<8>::scratch_doubles(sp->N);
-  const size_t nl = (sp->nv == 4) ? cmpc::Dims<4>::LDS_DOUBLES
+  // CMPC_EMU_PAIR=1 runs the 4-vertex solver as the pipelined pair of waves (two LDS images + the exchange words)
+  const bool pair = sp->nv == 4 && getenv("CMPC_EMU_PAIR") && atoi(getenv("CMPC_EMU_PAIR")) == 1;
+  const size_t nl = pair ? 2 * cmpc::Dims<4>::LDS_DOUBLES + 16 : (sp->nv == 4) ? cmpc::Dims<4>::LDS_DOUBLES
                     : (nw8 == 2)  ? cmpc::Dims<8, 2>::LDS_DOUBLES : cmpc::Dims<8>::LDS_DOUBLES;
   const double fill = getenv("CMPC_EMU_FILL") ? atof(getenv("CMPC_EMU_FILL")) : 0.0;
   std::vector<double> scratch(nd, fill), lds(nl, fill);
   ka.scratch = scratch.data(); ka.scratch_stride = nd;
   emu_barrier.count.store(0); emu_barrier.gen.store(0);
-  emu_barrier.width = (sp->nv == 8 && nw8 == 2) ? 128 : 64;
+  emu_barrier.width = ((sp->nv == 8 && nw8 == 2) || pair) ? 128 : 64;
   for (auto &b : emu_wave_barrier) { b.count.store(0); b.gen.store(0); b.width = 64; }
-  if (sp->nv == 4) run_batch<4, 1>(ka, lds.data());
+  if (pair) run_batch<4, 1, true>(ka, lds.data());
+  else if (sp->nv == 4) run_batch<4, 1>(ka, lds.data());
   else if (nw8 == 2) run_batch<8, 2>(ka, lds.data());
   else run_batch<8, 1>(ka, lds.data());
   return 0;

@@ -18,7 +18,9 @@ from conftest import oracle_spec, rel_inf  # noqa: E402
 emu = ctypes.CDLL(sys.argv[1])
 ol._LIB = ctypes.CDLL(sys.argv[2])
 p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
-for name, N, B, warm_start in (("long_horizon", 2, 1, False), ("long_horizon", 2, 1, True), ("perturbed", 2, 2, False)):
+for name, N, B, warm_start, pair in (("long_horizon", 2, 1, False, False), ("long_horizon", 2, 1, True, False),
+                                     ("perturbed", 2, 2, False, False), ("perturbed", 3, 2, False, True)):
+    os.environ["CMPC_EMU_PAIR"] = "1" if pair else "0"      # the pipelined pair of waves: two LDS images + exchange words
     spec, rec = wl.make_workload(name, B=B, N=N)
     cs = oracle_spec(ol, spec)
     rec = np.ascontiguousarray(rec)
@@ -30,6 +32,6 @@ for name, N, B, warm_start in (("long_horizon", 2, 1, False), ("long_horizon", 2
     out, st, it, kk = np.zeros((B, nsol)), np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
     assert emu.cmpc_emu_solve_batch(ctypes.byref(cs), B, p(rec), p(warm), p(out), p(st), p(it), p(kk)) == 0
     err = rel_inf(out, ref).max()
-    print(name, "nv", spec.nv, "warm" if warm_start else "cold", "status", st.tolist(), "err", err)
+    print(name, "nv", spec.nv, "pair" if pair else "", "warm" if warm_start else "cold", "status", st.tolist(), "err", err)
     assert np.isin(st, (0, 3)).all() and err < 1e-6
 print("sanitized run ok")

@@ -102,3 +102,33 @@ def test_regression_walk_tick_with_ill_conditioned_end_game(emu, oracle):
     ref, st_ref, it_ref, kk_ref = oracle.solve_batch(cs, rec, warm=warm)
     assert st[0] in (0, 3) and kk[0] < 1e-7 and it[0] <= 45
     assert st_ref[0] == 0 and rel_inf(got, ref).max() < 1e-4
+
+
+def test_pipelined_pair_of_waves_is_bitwise_the_single_wave(emu, oracle, monkeypatch):
+    """Solver<4, 1, PIPE>: wave 1 evaluates stage k - 1 into one LDS image while wave 0 runs the Riccati step of stage k out
+    of the other (small batches: the reference's own use is one instance per tick, code/simulation.py:203-204).  Same
+    arithmetic in the same order: solutions, iteration counts, KKT errors and solver states must be bit for bit those of
+    the single wave -- cold, resumed from the state, with a factorisation retry on the way, LDS and slab NaN-filled, and
+    several instances through one workgroup (image / exchange words reused)."""
+    monkeypatch.setenv("CMPC_EMU_FILL", "nan")
+    p = lambda a: None if a is None else np.ascontiguousarray(a).ctypes.data_as(ctypes.c_void_p)
+
+    def run(cs, rec, pair, warm=None, state=None):
+        monkeypatch.setenv("CMPC_EMU_PAIR", "1" if pair else "0")
+        B = rec.shape[0]
+        out, so = np.zeros((B, oracle.nsol(cs))), np.zeros((B, oracle.nstate(cs)))
+        st, it, kk = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
+        assert emu.cmpc_emu_solve_batch_state(ctypes.byref(cs), B, p(rec), p(warm), p(state), p(out), p(so), p(st), p(it), p(kk)) == 0
+        return out, so, st, it, kk
+    for name, B, N in (("randomized", 4, 6), ("perturbed", 2, 10), ("payload", 1, 1)):
+        spec, rec = wl.make_workload(name, B=B, N=N)
+        cs = oracle_spec(oracle, spec)
+        a, b = run(cs, rec, False), run(cs, rec, True)
+        assert np.isin(a[2], (0, 3)).all()
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        c, d = run(cs, rec, False, warm=a[0], state=a[1]), run(cs, rec, True, warm=a[0], state=a[1])
+        assert c[3].sum() < a[3].sum() or N <= 1                # resumed: fewer iterations
+        for x, y in zip(c, d):
+            assert np.array_equal(x, y)
+    assert emu.cmpc_emu_lds_bytes(4) * 2 + 128 + 16 <= 163840 // 2   # two pairs per CU

@@ -409,3 +409,41 @@ def test_batched_closed_loop_rollout(gpu, scene):
     err = np.abs(hist - ref[:, None, :])
     assert err[..., :2].max() < 0.05 and err[..., 2].max() < 0.02   # the Lyapunov controller holds the reference
     assert int(ro.t[0].item()) == t0 + ticks
+
+
+def test_pair_kernel_is_bitwise_the_single_wave_kernel(gpu, monkeypatch):
+    """Small batches run two waves per instance (cmpc_solve_pair_kernel: evaluation of stage k - 1 beside the Riccati step of
+    stage k).  Same arithmetic, same order: everything the call returns must be bit for bit what the one-wave kernel
+    returns -- B = 1, a batch larger than the pair kernel's resident grid (several instances through one workgroup),
+    cold and resumed from the solver state, the payload gains, the horizon limits of the build."""
+    def both(spec, rec, warm=None, state=None):
+        res = []
+        for pair in ("0", "1"):
+            monkeypatch.setenv("CMPC_PAIR", pair)              # developer knob read by cmpc_create: never / always
+            s = gpu(spec, device="cuda:0")
+            d = torch.from_numpy(np.ascontiguousarray(rec)).cuda()
+            so = s.new_state(rec.shape[0])
+            out, st, it, kkt = s.solve(d, warm=warm, state=state, state_out=so)
+            torch.cuda.synchronize()
+            res.append((out.clone(), st.clone(), it.clone(), kkt.clone(), so.clone(), s.last_kernel_ms()))
+        for x, y in zip(res[0][:5], res[1][:5]):
+            assert torch.equal(x, y)
+        return res
+    for name, B, N in (("randomized", 1, 20), ("randomized", 1100, 20), ("payload", 96, 10), ("perturbed", 5, 1), ("perturbed", 3, 64)):
+        spec, rec = wl.make_workload(name, B=B, N=N)
+        a = both(spec, rec)
+        assert np.isin(a[0][1].cpu().numpy(), (0, 3)).mean() > 0.9
+        b = both(spec, rec, warm=a[0][0], state=a[0][4])       # resumed
+        if B == 1 and N == 20:
+            assert a[1][5] < 0.85 * a[0][5], (a[0][5], a[1][5])  # and an instance alone on the GPU finishes sooner
+    monkeypatch.delenv("CMPC_PAIR")
+    # the entry point picks the pair kernel by itself when the batch does not fill the GPU: same results either way
+    spec, rec = wl.make_workload("randomized", B=64, N=20)
+    auto = gpu(spec, device="cuda:0")
+    o1, s1, i1, _ = auto.solve(torch.from_numpy(rec).cuda())
+    monkeypatch.setenv("CMPC_PAIR", "0")
+    single = gpu(spec, device="cuda:0")
+    o2, s2, i2, _ = single.solve(torch.from_numpy(rec).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(i1, i2)
+    assert auto.last_kernel_ms() < 0.9 * single.last_kernel_ms()
