@@ -11,6 +11,10 @@ twin of this loop is ``walk.WalkHarness`` around the drop-in class):
      to the MPC's own prediction x_1 (perfect-tracking centroidal model standing in for simulator +
      whole-body controller), optionally disturbed by a velocity push.  The angular momentum is either the MPC's
      prediction or an exogenous measured signal ``hw_measured[t] (+ per-instance offset)`` (see walk.py).
+  4. optionally the consumer of the tick, the whole-body inverse-dynamics QP (code/inverse_dynamics.py:30-134, called
+     from code/simulation.py:214-232 with ``desired['com']`` = the MPC's CoM position / velocity / acceleration): a
+     batched ``wbc.BatchedInverseDynamicsQP`` fed by the caller's rigid-body model (``attach_whole_body``), so that the
+     whole tick -- records, MPC solve, write-back, QP -- stays on the device.
 Everything after the solve is index arithmetic and copies in torch (device memory plumbing); the schedule
 (phases, step indices) is shared by the batch, the plan positions are per instance.
 """
@@ -51,6 +55,29 @@ class BatchedRollout:
         self._wb_row = torch.from_numpy(np.where(scene.support_is_l, 17, 13).astype(np.int64)).to(dev)
         self.hw_measured = None if hw_measured is None else torch.as_tensor(np.asarray(hw_measured), dtype=f64, device=dev)
         self.hw_offset = None if hw_offset is None else torch.as_tensor(np.asarray(hw_offset), dtype=f64, device=dev)
+        self._gl = torch.from_numpy(np.ascontiguousarray(scene.gl_tab)).to(dev)
+        self._gr = torch.from_numpy(np.ascontiguousarray(scene.gr_tab)).to(dev)
+        self._wbc = None
+
+    def attach_whole_body(self, qp, model):
+        """Run the whole-body QP inside every tick.  ``qp``: a ``wbc.BatchedInverseDynamicsQP``; ``model(rollout, desired)``
+        returns the device tensors (Hq, Fq, M, h, Jc) of its ``solve`` from the caller's rigid-body library (DART in the
+        reference, code/inverse_dynamics.py:46-66, :107-111) and ``desired`` = dict(com_pos, com_vel, com_acc (B,3),
+        gamma_l, gamma_r (B,)) -- what code/simulation.py:214-232 hands over from the MPC's ``model_state``.  The
+        result of the last tick is kept in ``last_wbc`` = (tau (B,24), qdd, f_c, status, iters)."""
+        self._wbc = (qp, model)
+        self.last_wbc = None
+
+    def desired_com(self, x1, u0, t):
+        """``model_state['com']`` of the reference's back half (:633-649) for the batch: position and velocity of x_1 and
+        CoM_acc = (gamma_l sum F_l + gamma_r sum F_r) / m + (0, 0, -g) from u_0 and the contact flags at tick t."""
+        nv = self.spec.nv
+        tl = torch.clamp(t.long(), max=self._gl.shape[0] - 1)
+        gl, gr = self._gl[tl], self._gr[tl]
+        F = u0[:, :6 * nv].reshape(-1, 2, nv, 3).sum(dim=2)                  # (B, foot, 3)
+        acc = (gl[:, None] * F[:, 0] + gr[:, None] * F[:, 1]) / self.state[:, 14:15]
+        acc = acc + torch.tensor([0.0, 0.0, -self.spec.g], dtype=torch.float64, device=self.device)
+        return {"com_pos": x1[:, 0:3], "com_vel": x1[:, 3:6], "com_acc": acc, "gamma_l": gl, "gamma_r": gr}
 
     def _hw_at(self, t):
         h = self.hw_measured[torch.clamp(t.long(), max=self.hw_measured.shape[0] - 1)]
@@ -87,6 +114,9 @@ class BatchedRollout:
         x1 = XU[:, 20:40]
         u0 = XU[:, 20 * (N + 1):20 * (N + 1) + sp.nu]
         self.last_records, self.last_XU, self.last_status, self.last_iters = rec, XU, status, iters
+        if self._wbc is not None:                # the consumer of the tick: whole-body QP on the same stream, no host hop
+            qp, model = self._wbc
+            self.last_wbc = qp.solve(*model(self, self.desired_com(x1, u0, self.t)))
         # plan write-back (:656-675), per instance
         tl = self.t.long()
         if self.update_contact:

@@ -154,3 +154,56 @@ def test_batched_rollout_walk_256(gpu, scene):
     assert err[..., :2].max() < 0.05 and err[..., 2].max() < 0.02
     moved = (ro.plan_pos.cpu().numpy() != scene.plan_pos[None]).any(axis=2)   # (B, n_steps)
     assert (moved.sum(axis=1) == 3).all()                      # three write-backs per instance (t = 261, 361, 461)
+
+
+def test_whole_tick_on_the_device_mpc_then_whole_body_qp(gpu, scene):
+    """SURVEY 8f rows 2 + 4 together: records -> MPC solve -> plan write-back -> whole-body QP, every tick, for 64 robots,
+    all on the device (code/simulation.py:193-232 per robot: customPreStep solves the MPC, then get_joint_torques solves
+    the QP with desired['com'] from the MPC's model_state).  The rigid-body model is a synthetic stand-in of the
+    reference's shapes (DART is not available): fixed task Jacobians per robot, the CoM task's feed-forward acceleration
+    = the MPC's CoM_acc (:633-636).  Every QP must converge, follow the commanded CoM acceleration, and equal the numpy
+    oracle of the QP on the same matrices."""
+    from cmpc_amd import wbc
+    from cmpc_amd.rollout import BatchedRollout
+    from oracle import wbc_qp_oracle as wq
+    spec = ProblemSpec(N=10)
+    B = 64
+    ro = BatchedRollout(scene, spec, B, device="cuda:0")
+    Hq0, Fq0, M, h, Jc = (torch.from_numpy(a).cuda() for a in wl.wbc_synthetic(B, seed=77))
+    rng = np.random.default_rng(5)
+    Jcom = torch.from_numpy(rng.normal(0, 0.4, size=(B, 3, 30))).cuda()
+    Jcom[:, :, 3:6] += torch.eye(3, dtype=torch.float64, device="cuda:0")
+    w_com = 50.0                                                            # the CoM task on top of the posture tasks
+    Hq = (Hq0 + w_com * Jcom.transpose(1, 2) @ Jcom).contiguous()
+    seen = []
+
+    def model(rollout, desired):
+        # contact Jacobian rows scaled by the contact flags (code/inverse_dynamics.py:109); CoM task gradient from the MPC
+        g = torch.cat([desired["gamma_l"][:, None].expand(-1, 6), desired["gamma_r"][:, None].expand(-1, 6)], dim=1)
+        Fq = (Fq0 - w_com * torch.einsum("brn,br->bn", Jcom, desired["com_acc"])).contiguous()
+        Jc_t = (Jc * g[:, :, None]).contiguous()
+        seen.append((Fq, Jc_t, desired["com_acc"].clone()))
+        return Hq, Fq, M, h, Jc_t
+    qp = wbc.BatchedInverseDynamicsQP(foot_size=0.1, mu=0.5, device="cuda:0")
+    ro.attach_whole_body(qp, model)
+    t0 = 255                                                                # single support, touch-down inside the run
+    com, dcom = scene.nominal_state(np.full(B, t0))
+    ro.reset(t0, com + rng.uniform(-0.003, 0.003, size=(B, 3)), dcom, hw=rng.normal(0, 0.05, size=(B, 3)))
+    for i in range(12):
+        _, _, status = ro.step()
+        tau, qdd, fc, st_q, it_q = ro.last_wbc
+        assert bool(np.isin(status.cpu().numpy(), (0, 3)).all()) and bool((st_q == 0).all())
+        assert tau.shape == (B, 24) and bool(torch.isfinite(tau).all())
+        Fq, Jc_t, acc = seen[-1]
+        # the commanded CoM acceleration is followed (the CoM task dominates its directions)
+        got = torch.einsum("brn,bn->br", Jcom, qdd)
+        assert float((got - acc).abs().max()) < 0.35 * max(1.0, float(acc.abs().max()))
+        # a foot in the air carries no wrench (its Jacobian rows are zero: 1e-6 |f|^2 alone holds f at 0)
+        air_l = seen[-1][1][:, 0:6].abs().sum(dim=(1, 2)) == 0
+        assert float(fc[air_l][:, 0:6].abs().max()) < 1e-6 if bool(air_l.any()) else True
+    # last tick against the numpy oracle of the QP, first three robots
+    for b in range(3):
+        ref = wq.solve(Hq[b].cpu().numpy(), Fq[b].cpu().numpy(), M[b].cpu().numpy(), h[b].cpu().numpy(), Jc_t[b].cpu().numpy(), 0.05, 0.5)
+        assert ref["status"] == 0
+        assert np.abs(qdd[b].cpu().numpy() - ref["qdd"]).max() < 1e-6 * max(1.0, np.abs(ref["qdd"]).max())
+        assert np.abs(tau[b].cpu().numpy() - ref["tau"][6:]).max() < 1e-6 * max(1.0, np.abs(ref["tau"]).max())

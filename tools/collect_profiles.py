@@ -24,7 +24,8 @@ def write(name, table):
 
 
 for name in ("bench_line.json", "bench_line_perturbed.json", "bench_line_payload.json", "bench_line_long_horizon.json",
-             "walk_demo.txt", "parity_report.txt", "full_parity.txt", "selflaunch_2rank.json"):
+             "walk_demo.txt", "parity_report.txt", "full_parity.txt", "selflaunch_2rank.json", "tail_randomized.txt",
+             "tail_long_horizon.txt", "bench_line_seed777.json", "bench_line_perturbed_single_wave.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
@@ -56,6 +57,25 @@ if os.path.exists(tr):
     res["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
                       f"--steps 1 --warmup 0 --no-cpu-baseline --no-extras   (tools/profile_round.sh {tag})")
     json.dump(res, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+# whole-body QP kernel: statistics of three launches, HBM counters of one (16 B / lane accesses are not used there: the
+# FETCH_SIZE correction of the 8 B / lane calibration above applies to its row loads as well)
+wk = one("wbc_stats/**/*kernel_stats.csv")
+if wk:
+    write("wbc_kernel_stats.csv", rows(wk, lambda x, h: "wbc_qp" in x[h.index("Name")]))
+    wb = {}
+    for d, key in (("wbc_fetch", "FETCH_SIZE"), ("wbc_write", "WRITE_SIZE")):
+        cc = one(f"{d}/**/*counter_collection.csv")
+        if cc:
+            wb[key + "_kb"] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(cc))
+                                  if "wbc_qp" in r["Kernel_Name"] and r["Counter_Name"] == key)
+    if wb:
+        tr_ = os.path.join(src, "traffic_raw.json")
+        ff = json.load(open(tr_)).get("fetch_factor", 2.0) if os.path.exists(tr_) else 2.0
+        wb["fetch_factor_applied"] = ff
+        wb["hbm_bytes_per_launch"] = wb.get("FETCH_SIZE_kb", 0.0) * 1024 * ff + wb.get("WRITE_SIZE_kb", 0.0) * 1024
+        wb["batch"] = 65536
+        wb["algorithmic_bytes_per_launch"] = 65536 * (8 * (2 * 900 + 2 * 30 + 360 + 30 + 30 + 12) + 8)
+        json.dump(wb, open(os.path.join(dst, f"{tag}_wbc_traffic.json"), "w"), indent=1)
 # stall summary: sum every counter of the solve kernel over the passes of tools/pmc_stall.sh
 tot = {}
 for cc in glob.glob(os.path.join(src, "pmc_stall", "**", "*counter_collection.csv"), recursive=True):

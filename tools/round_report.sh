@@ -10,6 +10,16 @@ python bench.py --workload perturbed --batch 256 --steps 6 --warmup 1 --no-extra
 python bench.py --workload payload --batch 4096 --steps 6 --warmup 1 --no-extras --no-cpu-baseline > "$out/bench_line_payload.json" 2>/dev/null
 python bench.py --workload long_horizon --steps 4 --warmup 1 --no-extras --no-cpu-baseline > "$out/bench_line_long_horizon.json" 2>/dev/null
 echo "config lines done"
+# the whole-body QP kernel: kernel statistics and HBM counters of three B = 65536 launches / one launch
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/wbc_stats" -- python3 tools/wbc_profile.py > "$out/wbc_stats.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/wbc_fetch" -- python3 tools/wbc_profile.py 1 > "$out/wbc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/wbc_write" -- python3 tools/wbc_profile.py 1 > "$out/wbc_write.log" 2>&1
+echo "wbc profile done"
+python tools/tail_study.py randomized 8192 > "$out/tail_randomized.txt" 2>&1
+python tools/tail_study.py long_horizon 2048 > "$out/tail_long_horizon.txt" 2>&1
+python bench.py --seed 777 --steps 6 --warmup 1 --no-extras --no-cpu-baseline > "$out/bench_line_seed777.json" 2>/dev/null
+CMPC_PAIR=0 python bench.py --workload perturbed --batch 256 --steps 6 --warmup 1 --no-extras --no-cpu-baseline > "$out/bench_line_perturbed_single_wave.json" 2>/dev/null
 python tools/walk_demo.py > "$out/walk_demo.txt" 2>&1; tail -2 "$out/walk_demo.txt"
 python tools/parity_report.py > "$out/parity_report.txt" 2>&1; echo "parity report done"
 for w in "randomized 8192" "payload 4096" "perturbed 4096"; do python tools/full_parity.py $w; done > "$out/full_parity.txt" 2>&1; tail -4 "$out/full_parity.txt"
