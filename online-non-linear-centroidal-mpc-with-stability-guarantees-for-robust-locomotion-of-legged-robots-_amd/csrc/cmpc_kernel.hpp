@@ -2049,7 +2049,13 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
           }
         }
       }
-      if (polish == 0) { st = CMPC_CONVERGED; break; }
+      if (polish == 0) {
+        // (a polish step that ends ABOVE the tolerance, with a larger error than the point that met it: that point,
+        // written out before the polish, is what is returned -- see the oracle)
+        st = CMPC_CONVERGED;
+        if (kkt > tol && kkt > ks) { kkt = ks; use_saved = true; }
+        break;
+      }
       // a resumed solve still at the state's barrier value: the state does not fit this tick's problem
       const bool stale = resume && it >= RESUME_RECENTRE_ITERS && polish < 0 && mu == st_in[D::state_mu(N)];
       const bool at_cap = it == sp.max_iter - spent;

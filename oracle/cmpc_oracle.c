@@ -816,7 +816,15 @@ static void solve_one_capped(const cmpc_spec *sp, const double *rec, const doubl
         }
       }
     }
-    if (polish == 0) { st->status = CMPC_CONVERGED; break; }
+    if (polish == 0) {
+      /* The polish step is there to land on the mu = tol/10 central-path point whichever path led to the tolerance.  Where
+       * it ends ABOVE the tolerance with a larger error than the point that met it (an inertia correction in the polish
+       * step, a saddle-type end point: up to 100 * tol passed as "converged" in rounds 1-3 and replaced the better
+       * point), that point -- written to `out` before the polish -- is what is returned. */
+      st->status = CMPC_CONVERGED;
+      if (kkt > tol && kkt > kkt_saved) { kkt = kkt_saved; use_saved = 1; }
+      break;
+    }
     /* a resumed solve that is still at the state's barrier value after RESUME_RECENTRE_ITERS iterations: the state does
      * not fit this tick's problem (a push, a re-planned contact); give up here instead of crawling to the cap -- the
      * plain solve follows with the rest of the budget (round-3 advisor: one stale state stretched a closed-loop launch

@@ -123,7 +123,7 @@ def test_independent_pins(gpu, oracle, path):
     # (status 0: the tolerance was met, the polish step that follows may leave up to 100 * tol; status 3: within acc_tol)
     assert (st[0] == 0 and kkt[0] < 1e-7) or (st[0] == 3 and kkt[0] <= 1e-8), (st, kkt)
     cs = oracle_spec(oracle, spec)
-    check_against_pin(pin, got[0], lambda w: oracle.evaluate(cs, pin["record"], w))
+    check_against_pin(pin, got[0], lambda w: oracle.evaluate(cs, pin["record"], w), kkt=float(kkt[0]))
 
 
 def test_edge_cases_empty_single_and_ragged_batches(gpu, oracle):

@@ -18,8 +18,34 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FILES = sorted(glob.glob(os.path.join(GOLD, "independent_pin_*.npz")))
 
 
-def check_against_pin(pin, sol, evaluate):
-    """`sol`: a solver's answer for pin['record'];  evaluate(w) -> (cost, defects, ineq, act)."""
+def flat_group_rel_inf(a, b, N, nu):
+    """rel-inf error of the foot-velocity inputs alone (group floor 0.1, as in conftest.group_rel_inf)."""
+    Ua, Ub = a[20 * (N + 1):].reshape(N, nu)[:, nu - 8:], b[20 * (N + 1):].reshape(N, nu)[:, nu - 8:]
+    return np.abs(Ua - Ub).max() / max(np.abs(Ub).max(), 1e-1)
+
+
+def determined_rel_inf(a, b, N, nu):
+    """(worst group error over everything but the foot-velocity inputs and the foot poses, error of the foot poses)."""
+    a2, b2 = a.copy(), b.copy()
+    a2[20 * (N + 1):].reshape(N, nu)[:, nu - 8:] = 0.0
+    b2[20 * (N + 1):].reshape(N, nu)[:, nu - 8:] = 0.0
+    Xa, Xb = a[:20 * (N + 1)].reshape(N + 1, 20)[:, 12:20], b[:20 * (N + 1)].reshape(N + 1, 20)[:, 12:20]
+    feet = np.abs(Xa - Xb).max() / max(np.abs(Xb).max(), 1e-2)
+    a2[:20 * (N + 1)].reshape(N + 1, 20)[:, 12:20] = 0.0
+    b2[:20 * (N + 1)].reshape(N + 1, 20)[:, 12:20] = 0.0
+    return group_rel_inf(a2, b2, N, nu)[0], feet
+
+
+def check_against_pin(pin, sol, evaluate, kkt=0.0):
+    """`sol`: a solver's answer for pin['record'];  evaluate(w) -> (cost, defects, ineq, act);  kkt: the solver's final
+    scaled KKT error for it.
+
+    Levels, stated from the problem.  Everything the problem determines (states, contact forces) is compared at `lim`.  The
+    foot-velocity inputs of an airborne foot are a flat direction: how a swing displacement is split over its stages is
+    held by the proximal weight rho = 1e-4 alone, so a point with scaled KKT error kkt sits within kkt * s_d / rho of the
+    optimum there (s_d = mean multiplier / 100 <= 100 on these records: multipliers reach 1e+4) -- 1e+6 * kkt -- and the
+    foot poses that integrate them (delta = 0.01, a ten times smaller scale) within 1e+5 * kkt; the objective must agree
+    to 1e-9 whatever the split."""
     N, nu = int(pin["N"]), 6 * int(pin["nv"]) + 8
     anchors = 0
     # 8-vertex patches: the split of a foot's force over eight vertices is held by the 1e-4 proximal weight alone, so a
@@ -29,7 +55,9 @@ def check_against_pin(pin, sol, evaluate):
     lim = 1e-5 if int(pin["nv"]) == 4 else 3e-5
     if float(pin["ipm_dense_kkt"]) <= 1e-7:                     # dense interior point, full Newton steps (no safeguards:
         # it may hover just above its 1e-9 tolerance, or fail outright -- then the other solver anchors the case)
-        assert rel_inf(sol, pin["sol_ipm_dense"])[0] < lim and group_rel_inf(sol, pin["sol_ipm_dense"], N, nu)[0] < lim
+        det, feet = determined_rel_inf(sol, pin["sol_ipm_dense"], N, nu)
+        assert rel_inf(sol, pin["sol_ipm_dense"])[0] < lim and det < lim
+        assert flat_group_rel_inf(sol, pin["sol_ipm_dense"], N, nu) < max(lim, 1e6 * kkt) and feet < max(lim, 1e5 * kkt)
         f_s, f_d = evaluate(sol)[0], evaluate(pin["sol_ipm_dense"])[0]
         assert abs(f_s - f_d) <= 1e-9 * abs(f_d)
         anchors += 1
@@ -75,4 +103,4 @@ def test_oracle_reproduces_independent_pins(oracle, path):
     sol, st, it, kkt = oracle.solve(cs, pin["record"])
     # (status 0: the tolerance was met, the polish step that follows may leave up to 100 * tol; status 3: within acc_tol)
     assert (st == 0 and kkt < 1e-7) or (st == 3 and kkt <= 1e-8), (st, kkt)
-    check_against_pin(pin, sol, lambda w: oracle.evaluate(cs, pin["record"], w))
+    check_against_pin(pin, sol, lambda w: oracle.evaluate(cs, pin["record"], w), kkt=float(kkt))
