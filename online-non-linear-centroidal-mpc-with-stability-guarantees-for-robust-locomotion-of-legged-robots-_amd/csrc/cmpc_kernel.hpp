@@ -1744,7 +1744,12 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         s3 += in ? al[h] * z : 0.0;
       }
       if constexpr (NW == 1) {
-        s0 = red_sum(s0); s1 = red_sum(s1); s2 = red_sum(s2); s3 = red_sum(s3);
+        // the four butterflies step together: six exchange round trips instead of twenty-four (same sums, same order)
+#pragma unroll 1
+        for (int mm = 32; mm >= 1; mm >>= 1) {
+          const double t0 = CMPC_XOR(s0, mm), t1 = CMPC_XOR(s1, mm), t2 = CMPC_XOR(s2, mm), t3 = CMPC_XOR(s3, mm);
+          s0 += t0; s1 += t1; s2 += t2; s3 += t3;
+        }
       } else {                                 // the four sums cross the waves in one exchange
 #pragma unroll 1
         for (int mm = 32; mm >= 1; mm >>= 1) {
