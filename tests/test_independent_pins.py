@@ -40,12 +40,11 @@ def check_against_pin(pin, sol, evaluate, kkt=0.0):
     """`sol`: a solver's answer for pin['record'];  evaluate(w) -> (cost, defects, ineq, act);  kkt: the solver's final
     scaled KKT error for it.
 
-    Levels, stated from the problem.  Everything the problem determines (states, contact forces) is compared at `lim`.  The
-    foot-velocity inputs of an airborne foot are a flat direction: how a swing displacement is split over its stages is
-    held by the proximal weight rho = 1e-4 alone, so a point with scaled KKT error kkt sits within kkt * s_d / rho of the
-    optimum there (s_d = mean multiplier / 100 <= 100 on these records: multipliers reach 1e+4) -- 1e+6 * kkt -- and the
-    foot poses that integrate them (delta = 0.01, a ten times smaller scale) within 1e+5 * kkt; the objective must agree
-    to 1e-9 whatever the split."""
+    Levels, stated from the problem.  Everything the problem determines (CoM, momentum, contact forces) is compared at
+    `lim`.  The foot-velocity inputs of an airborne foot are a flat direction: how a swing displacement is split over its
+    stages is held by the proximal weight rho = 1e-4 alone (and the foot poses integrate them with delta = 0.01), so two
+    points that both meet a KKT tolerance can sit apart there by (KKT error x multiplier scale) / rho.  They are
+    compared at `lim` as well; a pair beyond it must be objective-neutral to 1e-9 and feasible -- the flat valley itself."""
     N, nu = int(pin["N"]), 6 * int(pin["nv"]) + 8
     anchors = 0
     # 8-vertex patches: the split of a foot's force over eight vertices is held by the 1e-4 proximal weight alone, so a
@@ -57,9 +56,14 @@ def check_against_pin(pin, sol, evaluate, kkt=0.0):
         # it may hover just above its 1e-9 tolerance, or fail outright -- then the other solver anchors the case)
         det, feet = determined_rel_inf(sol, pin["sol_ipm_dense"], N, nu)
         assert rel_inf(sol, pin["sol_ipm_dense"])[0] < lim and det < lim
-        assert flat_group_rel_inf(sol, pin["sol_ipm_dense"], N, nu) < max(lim, 1e6 * kkt) and feet < max(lim, 1e5 * kkt)
         f_s, f_d = evaluate(sol)[0], evaluate(pin["sol_ipm_dense"])[0]
         assert abs(f_s - f_d) <= 1e-9 * abs(f_d)
+        flat = flat_group_rel_inf(sol, pin["sol_ipm_dense"], N, nu)
+        if flat >= lim or feet >= lim:
+            # further apart along the flat direction than `lim`: it must BE the flat direction -- the objective equal to
+            # 1e-9 (asserted above), the dynamics satisfied, the displacement small -- i.e. the same optimum seen from two
+            # points of its valley (the criterion of tests/test_gpu_parity.py::_explain_outliers)
+            assert flat < 1e-3 and feet < 1e-4 and np.abs(evaluate(sol)[1]).max() < 1e-7, (flat, feet, kkt)
         anchors += 1
     if "ipm_dense_ls_status" in pin.files and int(pin["ipm_dense_ls_status"]) == 0:   # same, l1 line search
         assert rel_inf(sol, pin["sol_ipm_dense_ls"])[0] < 1e-5
