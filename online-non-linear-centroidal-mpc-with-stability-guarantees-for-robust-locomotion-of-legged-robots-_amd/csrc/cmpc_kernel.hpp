@@ -476,55 +476,59 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       L(D::oMISC + dst) = acc;
     }
     sync();
-    // GH[a][col]: rows 6..8 of [B A] minus identity
+    // GH[a][col]: rows 6..8 of [B A] minus identity.  One batch of unconditional reads at clamped indices, then the column
+    // type picks its expression (as nested branches over the column type: four divergent paths with an exposed LDS round
+    // trip each; same expressions, the skipped terms of the per-foot sums are exact zeros: same bits).
     for (int col = lane; col < NZ; col += WS) {
-      double g0 = 0, g1 = 0, g2 = 0;
-      if (col < 6 * NV) {                    // force component: d*gamma*skew(r)[.][a]
-        const int v = col / 3, a = col % 3, f = v / NV;
-        const double g = d * L(D::oSR + 17 + f);
-        const double rx = L(D::oVR + 3 * v), ry = L(D::oVR + 3 * v + 1), rz = L(D::oVR + 3 * v + 2);
-        // column a of skew(r) = r x e_a, written branch-free
-        const double e0 = (a == 0) ? 1.0 : 0.0, e1 = (a == 1) ? 1.0 : 0.0, e2 = (a == 2) ? 1.0 : 0.0;
-        g0 = g * (ry * e2 - rz * e1); g1 = g * (rz * e0 - rx * e2); g2 = g * (rx * e1 - ry * e0);
-      } else if (col >= NU) {
-        const int s = col - NU;
-        if (s < 3 || (s >= 13 && s < 16) || (s >= 17 && s < 20)) {
-          // c_a: +d*sum_f gamma_f sum_j skew(f_j)[.][a];  p_{f,a}: -d*gamma_f sum_j skew(f_j)[.][a]
-          const int a = (s < 3) ? s : (s - 13) % 4;
-          double F0 = 0, F1 = 0, F2 = 0;
-          for (int f = 0; f < 2; ++f) {
-            if (s >= 13 && f != (s >= 17)) continue;
-            const double g = L(D::oSR + 17 + f);
-            F0 += g * L(D::oMISC + 3 * f); F1 += g * L(D::oMISC + 3 * f + 1); F2 += g * L(D::oMISC + 3 * f + 2);
-          }
-          const double e0 = (a == 0) ? 1.0 : 0.0, e1 = (a == 1) ? 1.0 : 0.0, e2 = (a == 2) ? 1.0 : 0.0;
-          const double sg = (s < 3) ? d : -d;
-          g0 = sg * (F1 * e2 - F2 * e1); g1 = sg * (F2 * e0 - F0 * e2); g2 = sg * (F0 * e1 - F1 * e0);
-        } else if (s == 12 || s == 16) {     // yaw: d*gamma_f sum_j (R'v_j) x f_j
-          const int f = (s == 16);
-          const double g = d * L(D::oSR + 17 + f);
-          g0 = g * L(D::oMISC + 21 + 3 * f); g1 = g * L(D::oMISC + 22 + 3 * f); g2 = g * L(D::oMISC + 23 + 3 * f);
-        }
-      }
+      const bool is_f = col < 6 * NV, is_x = col >= NU;
+      const int s = is_x ? col - NU : 0;
+      const bool is_cp = is_x && (s < 3 || (s >= 13 && s < 16) || (s >= 17 && s < 20)), is_yaw = is_x && (s == 12 || s == 16);
+      const int v = is_f ? col / 3 : 0, a = is_f ? col % 3 : (is_cp ? ((s < 3) ? s : (s - 13) % 4) : 0), f = v / NV;
+      const int fy = (s == 16) ? 1 : 0;
+      const double gm0 = L(D::oSR + 17), gm1 = L(D::oSR + 18);
+      const double rx = L(D::oVR + 3 * v), ry = L(D::oVR + 3 * v + 1), rz = L(D::oVR + 3 * v + 2);
+      const double M0 = L(D::oMISC + 0), M1 = L(D::oMISC + 1), M2 = L(D::oMISC + 2), M3 = L(D::oMISC + 3), M4 = L(D::oMISC + 4),
+                   M5 = L(D::oMISC + 5);
+      const double Y0 = L(D::oMISC + 21 + 3 * fy), Y1 = L(D::oMISC + 22 + 3 * fy), Y2 = L(D::oMISC + 23 + 3 * fy);
+      // column a of skew(.) = (.) x e_a, written branch-free
+      const double e0 = (a == 0) ? 1.0 : 0.0, e1 = (a == 1) ? 1.0 : 0.0, e2 = (a == 2) ? 1.0 : 0.0;
+      // force component: d*gamma*skew(r)[.][a]
+      const double gF = d * (f ? gm1 : gm0);
+      const double f0 = gF * (ry * e2 - rz * e1), f1 = gF * (rz * e0 - rx * e2), f2 = gF * (rx * e1 - ry * e0);
+      // c_a: +d*sum_f gamma_f sum_j skew(f_j)[.][a];  p_{f,a}: -d*gamma_f sum_j skew(f_j)[.][a]
+      const bool use0 = !(s >= 13 && (s >= 17)), use1 = !(s >= 13 && !(s >= 17));
+      double F0 = 0, F1 = 0, F2 = 0;
+      F0 += use0 ? gm0 * M0 : 0.0; F1 += use0 ? gm0 * M1 : 0.0; F2 += use0 ? gm0 * M2 : 0.0;
+      F0 += use1 ? gm1 * M3 : 0.0; F1 += use1 ? gm1 * M4 : 0.0; F2 += use1 ? gm1 * M5 : 0.0;
+      const double sg = (s < 3) ? d : -d;
+      const double c0 = sg * (F1 * e2 - F2 * e1), c1 = sg * (F2 * e0 - F0 * e2), c2 = sg * (F0 * e1 - F1 * e0);
+      // yaw: d*gamma_f sum_j (R'v_j) x f_j
+      const double gY = d * (fy ? gm1 : gm0);
+      const double y0 = gY * Y0, y1 = gY * Y1, y2 = gY * Y2;
+      const double g0 = is_f ? f0 : is_cp ? c0 : is_yaw ? y0 : 0.0;
+      const double g1 = is_f ? f1 : is_cp ? c1 : is_yaw ? y1 : 0.0;
+      const double g2 = is_f ? f2 : is_cp ? c2 : is_yaw ? y2 : 0.0;
       L(D::oGH + col) = g0; L(D::oGH + NZ + col) = g1; L(D::oGH + 2 * NZ + col) = g2;
     }
-    // b = F(x,u) - x_{k+1}
-    if (lane < NXA) {
-      const int q = lane;
-      double xn;
+    // b = F(x,u) - x_{k+1}: one batch of unconditional reads at clamped indices, then the row picks its expression (as an
+    // if / else-if chain over the row: nine divergent paths, an exposed LDS round trip each; same expressions, same bits)
+    {
+      const int q = (lane < NXA) ? lane : 0;
       const double *x = &L(D::oXK), *u = &L(D::oUK), *sr = &L(D::oSR);
-      if (q < 3) xn = x[q] + d * x[3 + q];
-      else if (q < 6) {
-        const int a = q - 3;
-        xn = x[q] + d * (((a == 2) ? -sp.g : 0.0) + (sr[17] * L(D::oMISC + a) + sr[18] * L(D::oMISC + 3 + a)) / m);
-      } else if (q < 9) xn = x[q] + d * L(D::oMISC + 6 + q - 6);
-      else if (q < 12) { const int a = q - 9; xn = x[q] + d / m * (sp.k1 * (x[a] - sr[a]) + x[3 + a] - sr[3 + a]); }
-      else if (q == 12) xn = x[12] + d * (1 - sr[17]) * u[6 * NV + 6];
-      else if (q < 16) xn = x[q] + d * (1 - sr[17]) * u[6 * NV + q - 13];
-      else if (q == 16) xn = x[16] + d * (1 - sr[18]) * u[6 * NV + 7];
-      else if (q < 20) xn = x[q] + d * (1 - sr[18]) * u[6 * NV + 3 + q - 17];
-      else xn = u[3 * (q - 20) + 2];
-      L(D::oBV + q) = xn - L(D::oXN1 + q);
+      const int a = (q < 3) ? q : (q < 6) ? q - 3 : (q >= 9 && q < 12) ? q - 9 : 0;     // axis of the CoM rows
+      const int ja = (q >= CMPC_NX) ? 3 * (q - CMPC_NX) + 2 : (q == 12) ? 6 * NV + 6 : (q >= 13 && q < 16) ? 6 * NV + q - 13
+                   : (q == 16) ? 6 * NV + 7 : (q >= 17 && q < 20) ? 6 * NV + 3 + q - 17 : 0;
+      const double own = x[(q < CMPC_NX) ? q : 0], xa = x[a], x3a = x[3 + a], sra = sr[a], sr3a = sr[3 + a];
+      const double g17 = sr[17], g18 = sr[18], ua = u[ja];
+      const double m_a = L(D::oMISC + a), m_3a = L(D::oMISC + 3 + a), m_tau = L(D::oMISC + 6 + ((q >= 6 && q < 9) ? q - 6 : 0));
+      const double xnext = L(D::oXN1 + q);
+      const double gsel = (q >= 16) ? g18 : g17;
+      const double xn = (q < 3) ? own + d * x3a
+                      : (q < 6) ? own + d * (((a == 2) ? -sp.g : 0.0) + (g17 * m_a + g18 * m_3a) / m)
+                      : (q < 9) ? own + d * m_tau
+                      : (q < 12) ? own + d / m * (sp.k1 * (xa - sra) + x3a - sr3a)
+                      : (q < CMPC_NX) ? own + d * (1 - gsel) * ua : ua;
+      if (lane < NXA) L(D::oBV + q) = xn - xnext;
     }
     sync();
   }
@@ -639,32 +643,39 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   // (Jg' w)[col] for the three weight vectors of a stage at once (multipliers z, sigma*(g+s), 1/s):
   // the same handful of LDS addresses in each, so one round trip serves all three.
   CMPC_DEV void jgt3(int k, int col, double (&out)[3]) const {
+    // Every word any column type needs is read unconditionally at clamped indices (one batch, one wait) and the column
+    // type only zeroes the coefficients of what it does not use: as an if / else-if chain over the column type this was
+    // four divergent paths with an exposed LDS round trip each (round 4; the sums pick up exact zeros, same bits).
     const double muf = L(D::oHDR + 21);
     const double *w0 = &L(D::oZK), *w1 = &L(D::oW1), *w2 = &L(D::oW2);
     const double alc = L(D::oAL + col);
     double v0 = alc * w0[R_LYAP], v1 = alc * w1[R_LYAP], v2 = alc * w2[R_LYAP];
-    if (col < 6 * NV) {
-      const int vtx = col / 3, a = col % 3, f = vtx / NV;
-      const double gg = (k < N) ? L(D::oSR + 17 + f) : 0.0;
-      const int b = R_FRIC + 5 * vtx;
-      // all fifteen words of the vertex's friction rows, then the axis picks its combination
-      const double p0 = w0[b], p1 = w0[b + 1], p2 = w0[b + 2], p3 = w0[b + 3], p4 = w0[b + 4];
-      const double q0 = w1[b], q1 = w1[b + 1], q2 = w1[b + 2], q3 = w1[b + 3], q4 = w1[b + 4];
-      const double r0 = w2[b], r1 = w2[b + 1], r2 = w2[b + 2], r3 = w2[b + 3], r4 = w2[b + 4];
+    const bool is_f = col < 6 * NV, is_x = col >= NU;
+    const int vtx = is_f ? col / 3 : 0, a = is_f ? col % 3 : 0, f = vtx / NV;
+    const int s = is_x ? col - NU : 0;
+    const bool s_cz = is_x && s == 2, s_hw = is_x && s >= 6 && s < 9;
+    const bool s_pos = is_x && ((s >= 13 && s < 16) || (s >= 17 && s < 20));
+    const int fp = (s >= 17) ? 1 : 0, ap = s_pos ? (s - 13) % 4 : 0;
+    const int b = R_FRIC + 5 * vtx, bb = R_BOX + 6 * fp + 2 * ap;
+    // all fifteen words of the vertex's friction rows, the height / contraction / box words of the state columns
+    const double p0 = w0[b], p1 = w0[b + 1], p2 = w0[b + 2], p3 = w0[b + 3], p4 = w0[b + 4];
+    const double q0 = w1[b], q1 = w1[b + 1], q2 = w1[b + 2], q3 = w1[b + 3], q4 = w1[b + 4];
+    const double r0 = w2[b], r1 = w2[b + 1], r2 = w2[b + 2], r3 = w2[b + 3], r4 = w2[b + 4];
+    const double c0 = w0[R_CZ], c1 = w1[R_CZ], c2 = w2[R_CZ], h0 = w0[R_HWC], h1 = w1[R_HWC], h2 = w2[R_HWC];
+    const double xs = L(D::oXK + (s_hw ? s : 6));
+    const double bx0 = w0[bb], bx0n = w0[bb + 1], bx1 = w1[bb], bx1n = w1[bb + 1], bx2 = w2[bb], bx2n = w2[bb + 1];
+    const double gs = L(D::oSR + 17 + f), gp = gam_k(k, fp);
+    if (is_f) {
+      const double gg = (k < N) ? gs : 0.0;
       const double ex = (a == 0) ? gg : 0.0, ey = (a == 1) ? gg : 0.0, ez = (a == 2) ? gg : 0.0;
       v0 += ex * (p0 - p1) + ey * (p2 - p3) - ez * (muf * ((p0 + p1) + (p2 + p3)) + p4);
       v1 += ex * (q0 - q1) + ey * (q2 - q3) - ez * (muf * ((q0 + q1) + (q2 + q3)) + q4);
       v2 += ex * (r0 - r1) + ey * (r2 - r3) - ez * (muf * ((r0 + r1) + (r2 + r3)) + r4);
-    } else if (col >= NU) {
-      const int s = col - NU;
-      if (s == 2) { v0 += w0[R_CZ]; v1 += w1[R_CZ]; v2 += w2[R_CZ]; }
-      else if (s >= 6 && s < 9) { const double xx = 2.0 * L(D::oXK + s); v0 += xx * w0[R_HWC]; v1 += xx * w1[R_HWC]; v2 += xx * w2[R_HWC]; }
-      else if ((s >= 13 && s < 16) || (s >= 17 && s < 20)) {
-        const int f = (s >= 17), a = (s - 13) % 4;
-        const double gg = (k >= 1) ? gam_k(k, f) : 0.0;
-        const int b = R_BOX + 6 * f + 2 * a;
-        v0 += gg * (w0[b] - w0[b + 1]); v1 += gg * (w1[b] - w1[b + 1]); v2 += gg * (w2[b] - w2[b + 1]);
-      }
+    } else if (s_cz) { v0 += c0; v1 += c1; v2 += c2; }
+    else if (s_hw) { const double xx = 2.0 * xs; v0 += xx * h0; v1 += xx * h1; v2 += xx * h2; }
+    else if (s_pos) {
+      const double gg = (k >= 1) ? gp : 0.0;
+      v0 += gg * (bx0 - bx0n); v1 += gg * (bx1 - bx1n); v2 += gg * (bx2 - bx2n);
     }
     out[0] = v0; out[1] = v1; out[2] = v2;
   }
@@ -1767,25 +1778,30 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       slack_dirs(s3);
       CMPC_TICK(17);
       // dx+ = b + [B A] (du, dx)
-      if (lane < NXA) {
-        const int q = lane;
+      {
+        // every word any row of [B A] needs, read unconditionally at clamped indices (one batch of LDS reads, one wait),
+        // then the row picks its expression: as an if / else-if chain over the row this was nine divergent paths with an
+        // exposed LDS round trip each (round 4; same expressions, same bits)
+        const int q = (lane < NXA) ? lane : 0;
         const double d = sp.delta;
         const double *dx = &L(cur), *du = &L(D::oUK);
-        double a = bq;
-        if (q < 3) a += dx[q] + d * dx[3 + q];
-        else if (q < 6) {
-          double fs = 0.0;
-          for (int v = 0; v < NF; ++v) fs += ((v < NV) ? gl : gr) * du[3 * v + q - 3];
-          a += dx[q] + d / m * fs;
-        } else if (q < 9) a += dx[q] + ((q == 6) ? s0 : (q == 7) ? s1 : s2);
-        else if (q < 12) a += dx[q] + d / m * (sp.k1 * dx[q - 9] + dx[q - 6]);
-        else if (q == 12) a += dx[12] + d * (1 - gl) * du[6 * NV + 6];
-        else if (q < 16) a += dx[q] + d * (1 - gl) * du[6 * NV + q - 13];
-        else if (q == 16) a += dx[16] + d * (1 - gr) * du[6 * NV + 7];
-        else if (q < 20) a += dx[q] + d * (1 - gr) * du[6 * NV + 3 + q - 17];
-        else a += du[3 * (q - 20) + 2];
-        gdx[(k + 1) * NXA + q] = a;
-        L(nxt + q) = a;
+        const int ia = (q < 3) ? 3 + q : ((q >= 9 && q < 12) ? q - 9 : 0), ib = (q >= 9 && q < 12) ? q - 6 : 0;
+        const int ja = (q >= CMPC_NX) ? 3 * (q - CMPC_NX) + 2 : (q == 12) ? 6 * NV + 6 : (q >= 13 && q < 16) ? 6 * NV + q - 13
+                     : (q == 16) ? 6 * NV + 7 : (q >= 17 && q < 20) ? 6 * NV + 3 + q - 17 : 0;
+        const int ax = (q >= 3 && q < 6) ? q - 3 : 0;
+        const double own = dx[(q < CMPC_NX) ? q : 0], xa = dx[ia], xb = dx[ib], ua = du[ja];
+        double fs = 0.0;
+#pragma unroll
+        for (int v = 0; v < NF; ++v) fs += ((v < NV) ? gl : gr) * du[3 * v + ax];
+        const double gsel = (q >= 16) ? gr : gl;
+        const double ssel = (q == 6) ? s0 : (q == 7) ? s1 : s2;
+        const double inc = (q < 3) ? own + d * xa : (q < 6) ? own + d / m * fs : (q < 9) ? own + ssel
+                         : (q < 12) ? own + d / m * (sp.k1 * xa + xb) : (q < CMPC_NX) ? own + d * (1 - gsel) * ua : ua;
+        const double a = bq + inc;
+        if (lane < NXA) {
+          gdx[(k + 1) * NXA + q] = a;
+          L(nxt + q) = a;
+        }
       }
       sync();
       { const int t = cur; cur = nxt; nxt = t; }
@@ -1794,24 +1810,24 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     ap = red_min(lap); ad = red_min(lad);
   }
 
-  // (Jg d)[r] of one stage: dx, du in LDS, hw = x_k[6..8], g0/g1 = the stage's contact flags
+  // (Jg d)[r] of one stage: dx, du in LDS, hw = x_k[6..8], g0/g1 = the stage's contact flags.  Every word any row type
+  // needs is read unconditionally at clamped indices -- one batch of LDS reads, one wait -- and the row type picks its
+  // combination: written as a chain of early returns this was nine divergent paths, each with its own exposed LDS round
+  // trip, in the middle of the forward sweep's serial part (round 4; same expressions, same bits).
   CMPC_DEV double jg_dot(int r, double lyap_dot, const double *dx, const double *du, double hw0, double hw1, double hw2,
                          double g0, double g1, double muf) const {
-    if (r == R_LYAP) return lyap_dot;
-    if (r == R_CZ) return dx[2];
-    if (r == R_HWC) return 2.0 * (hw0 * dx[6] + hw1 * dx[7] + hw2 * dx[8]);
-    if (r < R_FRIC) {
-      const int q = r - R_BOX, f = q / 6, a = (q % 6) / 2, sgn = (q & 1) ? -1 : 1;
-      return sgn * (f ? g1 : g0) * dx[13 + 4 * f + a];
-    }
-    const int q = r - R_FRIC, v = q / 5, t = q % 5, f = v / NV;
-    const double gg = f ? g1 : g0;
+    const bool is_box = r >= R_BOX && r < R_FRIC, is_fr = r >= R_FRIC;
+    const int qb = is_box ? r - R_BOX : 0, fb = qb / 6, ab = (qb % 6) / 2;
+    const int qf = is_fr ? r - R_FRIC : 0, v = qf / 5, t = qf % 5;
+    const double d2 = dx[2], d6 = dx[6], d7 = dx[7], d8 = dx[8], dbx = dx[13 + 4 * fb + ab];
     const double fx = du[3 * v], fy = du[3 * v + 1], fz = du[3 * v + 2];
-    if (t == 0) return gg * (fx - muf * fz);
-    if (t == 1) return gg * (-fx - muf * fz);
-    if (t == 2) return gg * (fy - muf * fz);
-    if (t == 3) return gg * (-fy - muf * fz);
-    return -gg * fz;
+    const int sgn = (qb & 1) ? -1 : 1;
+    const double v_box = sgn * (fb ? g1 : g0) * dbx;
+    const double gg = (v / NV) ? g1 : g0;
+    const double v_fr = (t == 0) ? gg * (fx - muf * fz) : (t == 1) ? gg * (-fx - muf * fz) : (t == 2) ? gg * (fy - muf * fz)
+                      : (t == 3) ? gg * (-fy - muf * fz) : -gg * fz;
+    const double v_hw = 2.0 * (hw0 * d6 + hw1 * d7 + hw2 * d8);
+    return (r == R_LYAP) ? lyap_dot : (r == R_CZ) ? d2 : (r == R_HWC) ? v_hw : (is_box ? v_box : v_fr);
   }
 
   CMPC_DEV void apply_step(double mu, double ap, double ad) {

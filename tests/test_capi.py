@@ -99,10 +99,14 @@ def test_kernel_isa_has_no_flat_memory_instructions(tmp_path):
     assert not bad, bad[:5]
 
 
-def test_four_vertex_kernel_uses_no_scratch(tmp_path):
-    """The hot kernel (cmpc_solve_kernel<4>) must not spill vector registers: a scratch reload is an exposed memory
-    round trip for a wave that has nothing else to run (round-2 review: Scratch_Size 96 B/lane, 30 VGPR spills).
-    Read from the code-object metadata of the cross-compiled kernel (.private_segment_fixed_size), no GPU needed."""
+def test_four_vertex_kernel_has_no_spill_code_in_its_stage_loops(tmp_path):
+    """The hot kernel (cmpc_solve_kernel<4>) must not spill vector registers where it matters: a scratch reload is an
+    exposed memory round trip for a wave that has nothing else to run (round-2 review: Scratch_Size 96 B/lane, 30 VGPR
+    spills, some of them inside the stage loops).  Read from the cross-compiled ISA and its code-object metadata, no GPU
+    needed: at most 16 bytes of scratch per lane, and every scratch instruction sits OUTSIDE the stage loops (loop depth
+    <= 3 = instance loop, attempt loop, iteration loop: executed once per iteration at most, against ~21 stages x
+    ~7000 instructions per iteration).  Round 3 had none at all; round 4's branch-free state-update rows (+1.8 %) cost
+    three registers kept across the vector sweep, saved and restored once per iteration."""
     import re
     import subprocess
     src = os.path.join(_b.PKG, "csrc", "cmpc_hip.hip")
@@ -117,8 +121,22 @@ def test_four_vertex_kernel_uses_no_scratch(tmp_path):
     scratch = int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", meta).group(1))
     spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1))
     lds = int(re.search(r"\.group_segment_fixed_size:\s*(\d+)", meta).group(1))
-    assert scratch == 0 and spills == 0, (scratch, spills)
+    assert scratch <= 16 and spills <= 4, (scratch, spills)
     assert 6 * ((lds + 1279) // 1280 * 1280) <= 160 * 1024      # six workgroups per CU (LDS comes in 1280-byte granules)
+    # loop depth of every basic block that holds a scratch instruction (the assembler comments carry it)
+    body = isa[isa.index("cmpc_solve_kernelILi4ELi1EEEvN4cmpc5KArgsEPiPKi:"):]
+    body = body[:body.index("s_endpgm")]
+    depth, worst, n = 0, 0, 0
+    for ln in body.splitlines():
+        m = re.match(r"^\.LBB\d+_\d+:(.*)$", ln)
+        if m:
+            d = re.search(r"Depth=(\d+)", m.group(1))
+            depth = int(d.group(1)) if d else 0
+        elif "This Inner Loop Header: Depth=" in ln or "This Loop Header: Depth=" in ln:
+            depth = int(re.search(r"Depth=(\d+)", ln).group(1))
+        elif ln.strip().startswith("scratch_"):
+            worst, n = max(worst, depth), n + 1
+    assert worst <= 3, f"{n} scratch instructions, deepest at loop depth {worst}: spill code inside a stage loop"
 
 
 def test_queue_order_coefficients_live_in_one_header():
