@@ -1,5 +1,5 @@
 """Developer script: how much of a launch is drain?  Solves a workload once, then replays the ticket queue on the host
-from the measured iteration counts: makespan (in instance-iterations) of the shipped order (contact-switch class first),
+from the measured iteration counts (env SEED: another draw of the workload): makespan (in instance-iterations) of the shipped order (contact-switch class first),
 of the input order and of longest-first with perfect knowledge, against the balanced bound sum / slots and the longest
 instance.  usage (GPU box): python tools/tail_study.py [workload] [B]"""
 import heapq, os, sys
@@ -12,7 +12,7 @@ from cmpc_amd.solver import BatchedCentroidalMPC
 
 name = sys.argv[1] if len(sys.argv) > 1 else "long_horizon"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-spec, rec = wl.make_workload(name, B=B)
+spec, rec = wl.make_workload(name, B=B, seed=int(os.environ["SEED"]) if os.environ.get("SEED") else None)
 if spec.N > 20:
     spec.max_iter = 150
 s = BatchedCentroidalMPC(spec, device="cuda:0")
