@@ -37,23 +37,35 @@ namespace {
 constexpr int ORDER_BUCKETS = 64;
 constexpr int ORDER_COUNTERS = 3 + 2 * ORDER_BUCKETS;
 
-__device__ __forceinline__ int cmpc_order_bucket(const double *__restrict__ r, int N, double omega) {
+// The features of a record that say how long its solve will take (mirrored by cmpc_amd/queue_order.py::features; the
+// coefficients: csrc/cmpc_order_fit.h).  Round 4 added the interactions and the velocity / friction terms: out of sample
+// over five seeds the replayed makespan falls from 1.35 to 1.31 x the balanced bound (tools/fit_queue_order.py).
+__device__ __forceinline__ int cmpc_order_bucket(const double *__restrict__ r, int N, double omega, double cz_max) {
   double gl = r[24 + 17], gr = r[24 + 18];
   const double gl0 = gl, gr0 = gr;
-  int first = N;
+  int first = N, nsw = 0;
+  double gain = 0.0;                                                        // 1: the first switch is a touch-down
   for (int k = 1; k <= N; ++k) {
     const double l = (k < N) ? r[24 + 19 * k + 17] : r[22], q = (k < N) ? r[24 + 19 * k + 18] : r[23];
-    if (first == N && ((l != gl) || (q != gr))) first = k - 1;
+    const bool ch = (l != gl) || (q != gr);
+    if (ch && first == N) { first = k - 1; gain = (l + q > gl + gr) ? 1.0 : 0.0; }
+    nsw += ch ? 1 : 0;
     gl = l; gr = q;
   }
   const double dx = r[0] + r[3] / omega, dy = r[1] + r[4] / omega;          // capture point of x_0
   const bool both = (gl0 != 0.0) == (gr0 != 0.0);                           // (no foot down: treated like both)
   const double tx = both ? 0.5 * (r[13] + r[17]) : (gl0 != 0.0) ? r[13] : r[17];
   const double ty = both ? 0.5 * (r[14] + r[18]) : (gl0 != 0.0) ? r[14] : r[18];
-  const double d2 = (dx - tx) * (dx - tx) + (dy - ty) * (dy - ty);
+  const double d2 = (dx - tx) * (dx - tx) + (dy - ty) * (dy - ty), d = sqrt(d2);
   const double hw = sqrt(r[6] * r[6] + r[7] * r[7] + r[8] * r[8]);
-  const double its = CMPC_ORDER_C0 + CMPC_ORDER_C_SWITCH * (first < N) + CMPC_ORDER_C_FIRST * first + CMPC_ORDER_C_FEET * (gl0 + gr0) +
-                     CMPC_ORDER_C_D * sqrt(d2) + CMPC_ORDER_C_D2 * d2 + CMPC_ORDER_C_HW * hw;      // csrc/cmpc_order_fit.h
+  const double evx = r[3] - r[24 + 3], evy = r[4] - r[24 + 4], ev2 = evx * evx + evy * evy, ev = sqrt(ev2);
+  const double sw = (first < N) ? 1.0 : 0.0, feet = gl0 + gr0, mu = r[21];
+  const double f[CMPC_ORDER_NFEAT] = {1.0, sw, (double)first, feet, d, d2, hw, d * sw, d * feet, gain, ev, (double)nsw,
+                                      cz_max - r[2], mu, r[20] / 40.0, ev2, ev * feet, 1.0 / mu};
+  const double c[CMPC_ORDER_NFEAT] = CMPC_ORDER_COEF;                        // csrc/cmpc_order_fit.h
+  double its = 0.0;
+#pragma unroll
+  for (int i = 0; i < CMPC_ORDER_NFEAT; ++i) its += c[i] * f[i];
   const double b = 2.0 * (its - CMPC_ORDER_BUCKET_ORIGIN);                   // buckets of half an iteration
   return (b > 0.0) ? ((b < ORDER_BUCKETS - 1) ? (int)b : ORDER_BUCKETS - 1) : 0;   // (a NaN record lands in bucket 0)
 }
@@ -62,7 +74,7 @@ __device__ __forceinline__ int cmpc_order_bucket(const double *__restrict__ r, i
 // first spare word: consecutive ticks of a closed loop take similar numbers of iterations.  One bucket per iteration
 // there; the formula's buckets (10 + b / 2 iterations) and these meet around 20 iterations, which is where a mixed
 // batch needs them comparable (an instance without a state is a cold solve).
-__global__ void __launch_bounds__(256) cmpc_order_score_kernel(int B, int N, double omega, const double *__restrict__ recs,
+__global__ void __launch_bounds__(256) cmpc_order_score_kernel(int B, int N, double omega, double cz_max, const double *__restrict__ recs,
                                                                const double *__restrict__ state_in, size_t nstate, size_t mu_word,
                                                                int *__restrict__ key, int *__restrict__ counters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,7 +84,7 @@ __global__ void __launch_bounds__(256) cmpc_order_score_kernel(int B, int N, dou
     const double ms = state_in[(size_t)i * nstate + mu_word], cnt = state_in[(size_t)i * nstate + mu_word + 1];
     if (ms > 0.0 && ms < INFINITY && cnt >= 1.0 && cnt < 1e6) b = (cnt < ORDER_BUCKETS - 1) ? (int)cnt : ORDER_BUCKETS - 1;
   }
-  if (b < 0) b = cmpc_order_bucket(recs + (size_t)i * CMPC_NREC(N), N, omega);
+  if (b < 0) b = cmpc_order_bucket(recs + (size_t)i * CMPC_NREC(N), N, omega, cz_max);
   key[i] = b;
   atomicAdd(counters + 3 + b, 1);
 }
@@ -395,7 +407,7 @@ int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, cons
   HIP_TRY(h, hipEventRecord(h->ev0, st));
   const double omega = sqrt(h->spec.g / h->spec.cz_max);                   // natural frequency of the pendulum at the height limit
   const size_t nstate = CMPC_NSTATE(h->spec.N, h->spec.nv), mu_word = nstate - 8 - 2 * (size_t)(h->spec.N + 1);
-  hipLaunchKernelGGL(cmpc_order_score_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->spec.N, omega, params, state_in, nstate,
+  hipLaunchKernelGGL(cmpc_order_score_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->spec.N, omega, h->spec.cz_max, params, state_in, nstate,
                      mu_word, h->order + B, h->ticket);
   hipLaunchKernelGGL(cmpc_order_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->order + B, h->order, h->ticket);
   if (h->spec.nv == 4 && B <= h->pair_grid)          // the batch does not fill the GPU: two waves per instance

@@ -144,11 +144,11 @@ def test_queue_order_coefficients_live_in_one_header():
     parses it, and nothing else spells the numbers out."""
     from cmpc_amd import queue_order as qo, workloads as wl
     coef, origin = qo.coefficients()
-    assert coef.shape == (7,) and 0 < origin < 40
+    assert coef.shape == (len(qo.NAMES),) and len(qo.NAMES) == 18 and 0 < origin < 40
     hip = open(os.path.join(_b.PKG, "csrc", "cmpc_hip.hip")).read()
-    assert '#include "cmpc_order_fit.h"' in hip and "CMPC_ORDER_C_D2" in hip
+    assert '#include "cmpc_order_fit.h"' in hip and "CMPC_ORDER_COEF" in hip and "CMPC_ORDER_NFEAT" in hip
     for path in (os.path.join(ROOT, "tools", "tail_study.py"), os.path.join(_b.PKG, "csrc", "cmpc_hip.hip")):
-        assert f"{coef[5]:.3f}" not in open(path).read()
+        assert f"{coef[5]:.4f}" not in open(path).read() and f"{coef[4]:.3f}" not in open(path).read()
     head = open(qo.FIT_HEADER).read()
     assert "NOT a BASELINE seed" in head
     for seed in (c[0] for c in wl.CONFIGS.values()):
