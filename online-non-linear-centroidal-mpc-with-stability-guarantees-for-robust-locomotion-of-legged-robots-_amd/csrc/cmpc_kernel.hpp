@@ -52,8 +52,35 @@ static __device__ __forceinline__ double cmpc_bcast(double v, int src) {
 // B[l>>4][l&15]; it receives D[(l>>4) + 4r][l&15] in component r (gfx950 f64 layout).
 typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 #define CMPC_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-// butterfly exchange for wave-wide reductions
-#define CMPC_XOR(v, m) __shfl_xor((v), (m))
+// Butterfly step of a wave-wide reduction: CMPC_PAIR_OF(M, v, a, b) leaves in {a, b} this lane's v and the v of lane ^ M
+// (as a SET: which of the two is which differs by lane, so it serves commutative combinations only -- a + b, fmax, fmin --
+// and those are then bit for bit the results of an exchange through ds_bpermute).  No LDS round trip: lanes 32 and 16
+// apart through gfx950's v_permlane32_swap / v_permlane16_swap (both operands = v: the two results are the lower and
+// the upper partner in every lane), 8 and 4 apart by a row rotate (DPP), 2 and 1 apart by a quad permute (DPP).  The
+// rotate by 4 reaches lane ^ 4 or lane ^ 4 ^ 8: the steps must run from 32 down, so that lanes 8 apart already agree.
+// Measured on an idle CU: 864 -> 184 cycles per six-step reduction of a double.
+template <int CTRL> static __device__ __forceinline__ double cmpc_dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int M> static __device__ __forceinline__ void cmpc_pair_of(double v, double &a, double &b) {
+  static_assert(M == 32 || M == 16 || M == 8 || M == 4 || M == 2 || M == 1, "butterfly distance");
+  if constexpr (M == 32) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto p = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), q = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    a = __hiloint2double((int)q[0], (int)p[0]); b = __hiloint2double((int)q[1], (int)p[1]);
+  } else if constexpr (M == 16) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto p = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), q = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    a = __hiloint2double((int)q[0], (int)p[0]); b = __hiloint2double((int)q[1], (int)p[1]);
+  } else {
+    a = v;                                   // row_ror:8, row_ror:4, quad_perm:[2,3,0,1], quad_perm:[1,0,3,2]
+    b = (M == 8) ? cmpc_dpp_mov<0x128>(v) : (M == 4) ? cmpc_dpp_mov<0x124>(v) : (M == 2) ? cmpc_dpp_mov<0x4e>(v) : cmpc_dpp_mov<0xb1>(v);
+  }
+}
+#define CMPC_PAIR_OF(M, v, a, b) cmpc_pair_of<M>((v), (a), (b))
 // makes a per-lane value opaque to the optimiser: stops loop-invariant code motion from hoisting the
 // hundreds of lane-derived index computations out of the stage / iteration loops (they were kept live
 // across the whole solve and spilled)
@@ -1599,21 +1626,22 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     sync();
     return (op == OP_MAX) ? fmax(a, b) : (op == OP_MIN) ? fmin(a, b) : a + b;
   }
+  // one butterfly step (the six run from 32 down: see CMPC_PAIR_OF)
+  template <int M> CMPC_DEV static double bfly_sum(double v) { double a, b; CMPC_PAIR_OF(M, v, a, b); return a + b; }
+  template <int M> CMPC_DEV static double bfly_max(double v) { double a, b; CMPC_PAIR_OF(M, v, a, b); return fmax(a, b); }
+  template <int M> CMPC_DEV static double bfly_min(double v) { double a, b; CMPC_PAIR_OF(M, v, a, b); return fmin(a, b); }
+  CMPC_DEV static double wave_sum(double v) {
+    v = bfly_sum<32>(v); v = bfly_sum<16>(v); v = bfly_sum<8>(v); v = bfly_sum<4>(v); v = bfly_sum<2>(v); return bfly_sum<1>(v);
+  }
   CMPC_DEV double red_max(double v) {
-#pragma unroll 1
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, CMPC_XOR(v, m));
+    v = bfly_max<32>(v); v = bfly_max<16>(v); v = bfly_max<8>(v); v = bfly_max<4>(v); v = bfly_max<2>(v); v = bfly_max<1>(v);
     return across_waves(v, OP_MAX);
   }
   CMPC_DEV double red_min(double v) {
-#pragma unroll 1
-    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, CMPC_XOR(v, m));
+    v = bfly_min<32>(v); v = bfly_min<16>(v); v = bfly_min<8>(v); v = bfly_min<4>(v); v = bfly_min<2>(v); v = bfly_min<1>(v);
     return across_waves(v, OP_MIN);
   }
-  CMPC_DEV double red_sum(double v) {
-#pragma unroll 1
-    for (int m = 32; m >= 1; m >>= 1) v += CMPC_XOR(v, m);
-    return across_waves(v, OP_SUM);
-  }
+  CMPC_DEV double red_sum(double v) { return across_waves(wave_sum(v), OP_SUM); }
 
   // ---------------------------------------------------------------------------------------
   // Forward sweep: du_k, dx_{k+1}, lam_k.  The factors are read from the slab straight into
@@ -1754,18 +1782,11 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         s0 += in ? gh[0][h] * z : 0.0; s1 += in ? gh[1][h] * z : 0.0; s2 += in ? gh[2][h] * z : 0.0;
         s3 += in ? al[h] * z : 0.0;
       }
-      if constexpr (NW == 1) {
-        // the four butterflies step together: six exchange round trips instead of twenty-four (same sums, same order)
-#pragma unroll 1
-        for (int mm = 32; mm >= 1; mm >>= 1) {
-          const double t0 = CMPC_XOR(s0, mm), t1 = CMPC_XOR(s1, mm), t2 = CMPC_XOR(s2, mm), t3 = CMPC_XOR(s3, mm);
-          s0 += t0; s1 += t1; s2 += t2; s3 += t3;
-        }
-      } else {                                 // the four sums cross the waves in one exchange
-#pragma unroll 1
-        for (int mm = 32; mm >= 1; mm >>= 1) {
-          s0 += CMPC_XOR(s0, mm); s1 += CMPC_XOR(s1, mm); s2 += CMPC_XOR(s2, mm); s3 += CMPC_XOR(s3, mm);
-        }
+      // the four butterflies step together (same sums, same order as four reductions one after the other)
+#define CMPC_STEP4(M) do { s0 = bfly_sum<M>(s0); s1 = bfly_sum<M>(s1); s2 = bfly_sum<M>(s2); s3 = bfly_sum<M>(s3); } while (0)
+      CMPC_STEP4(32); CMPC_STEP4(16); CMPC_STEP4(8); CMPC_STEP4(4); CMPC_STEP4(2); CMPC_STEP4(1);
+#undef CMPC_STEP4
+      if constexpr (NW != 1) {                 // the four sums cross the waves in one exchange
         if ((lane & 63) == 0) {
           double *w = (wv == 0) ? &L(D::oRED) : &R(D::oCOLD + 4);
           w[0] = s0; w[1] = s1; w[2] = s2; w[3] = s3;

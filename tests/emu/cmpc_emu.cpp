@@ -57,7 +57,8 @@ static inline double emu_xor(double v, int m) {
   emu_barrier_wait(&emu_wave_barrier[w]);
   return r;
 }
-#define CMPC_XOR(v, m) emu_xor((v), (m))
+// butterfly step: this lane's value and its partner's (the device gets them without an LDS round trip, see cmpc_kernel.hpp)
+#define CMPC_PAIR_OF(M, v, a, b) do { (a) = (v); (b) = emu_xor((v), (M)); } while (0)
 #define CMPC_SCHED_FENCE() do { } while (0)
 // emulated v_mfma_f64_16x16x4: every lane publishes its A / B element, then gathers its 4 results
 struct cmpc_v4d { double v[4]; double &operator[](int i) { return v[i]; } const double &operator[](int i) const { return v[i]; } };
