@@ -140,7 +140,7 @@ template <int NV>
 __global__ void __launch_bounds__(128, 1) cmpc_solve_pair_kernel(cmpc::KArgs ka, int *ticket,
                                                                                   const int *__restrict__ order) {
   using D = cmpc::Dims<NV, 1>;
-  __shared__ __attribute__((aligned(16))) double lds[2 * D::LDS_DOUBLES + 16];
+  __shared__ __attribute__((aligned(16))) double lds[2 * D::LDS_DOUBLES + cmpc::Solver<NV, 1, true>::XCH_DOUBLES];
   __shared__ int next;
   double *slab = ka.scratch + (size_t)blockIdx.x * ka.scratch_stride;
   const size_t nrec = CMPC_NREC(ka.sp.N), nsol = CMPC_NSOL(ka.sp.N, NV), nstate = CMPC_NSTATE(ka.sp.N, NV);
@@ -330,7 +330,7 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   if (spec->nv == 4) {
     // pairs a CU holds: LDS (two images) in 1280-byte granules; the pair kernel is built for one wave per SIMD (up to 512
     // registers), i.e. at most two pairs per CU
-    const size_t granule = 1280, alloc = (sizeof(double) * (2 * cmpc::Dims<4>::LDS_DOUBLES + 16) + 16 + granule - 1) / granule * granule;
+    const size_t granule = 1280, alloc = (sizeof(double) * (2 * cmpc::Dims<4>::LDS_DOUBLES + cmpc::Solver<4, 1, true>::XCH_DOUBLES) + 16 + granule - 1) / granule * granule;
     int n = (int)((160 * 1024) / alloc);
     if (n > 2) n = 2;
     h->pair_grid = h->num_cu * (n < 1 ? 1 : n);

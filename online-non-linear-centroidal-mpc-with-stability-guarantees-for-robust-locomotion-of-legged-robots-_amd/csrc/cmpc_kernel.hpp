@@ -327,6 +327,9 @@ struct GArr {
 // reference's own use is ONE instance per tick, code/simulation.py:203-204): an instance finishes ~1.4x sooner.
 template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   using D = Dims<NV, NW>;
+  // PIPE: words behind the two LDS images.  [0..5] error measures, [6] ap, [7] ad, [8..9] factorisation verdict of the
+  // sweep step in hand (by step parity), [16 ..): du_k of the forward sweep by stage parity (read by the slack wave)
+  static constexpr int XCH_DU = 16, XCH_DOUBLES = XCH_DU + 2 * D::NU;
   static_assert(!PIPE || NW == 1, "the pipelined pair runs the one-wave solver");
   static constexpr int NF = D::NF, NU = D::NU, NXA = D::NXA, NZ = D::NZ, NI = D::NI, NH = D::NH, WS = D::WS;
   static_assert(NW == 1 || NU <= 64, "the input rows (pivot chains, substitutions) live in the first wave");
@@ -1651,10 +1654,19 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   // dense rows of [B A] (angular momentum) are held one column per lane and reduced by butterflies.
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void vector_sweeps(double mu, double dmu, double &ap, double &ad) {
+    if constexpr (PIPE) {
+      // The pair splits the sweep: wave 0 keeps the serial chain (du_k, dx_{k+1}, lam_k), wave 1 forms the slack and
+      // multiplier directions of stage k and the step bounds from du_k (handed over by stage parity) and dx_k (wave 0's
+      // ping-pong buffer, rewritten two stages later).  One workgroup barrier per stage; same expressions on the same
+      // operands as the single wave.
+      image(0);
+      if (wv == 1) { slack_sweep(mu, ap, ad); return; }
+    }
     const double m = rec[20], muf = rec[21];
     constexpr int NIH = (NI + WS - 1) / WS;
     const double tau = fmax(0.99, 1 - mu);
     double lap = 1.0, lad = 1.0;
+    double *xdu = ldsR + 2 * D::LDS_DOUBLES + XCH_DU;
     constexpr bool MERGE = D::W_MERGE;
     const bool isA = lane < NU;
     const int lb = MERGE ? lane - NU : lane;
@@ -1677,14 +1689,17 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       const double gl = rec[(k < N) ? 24 + 19 * k + 17 : 22], gr = rec[(k < N) ? 24 + 19 * k + 18 : 23];
       // slack / multiplier directions of the stage are formed here too (one pass over the stages less)
       double al[NH], sv[NIH], zv[NIH], gv[NIH];
+      double hw0 = 0.0, hw1 = 0.0, hw2 = 0.0;
+      if constexpr (!PIPE) {
 #pragma unroll
-      for (int h = 0; h < NH; ++h) { const int c = lane + WS * h; al[h] = st[D::gAL + ((c < NZ) ? c : 0)]; }
+        for (int h = 0; h < NH; ++h) { const int c = lane + WS * h; al[h] = st[D::gAL + ((c < NZ) ? c : 0)]; }
 #pragma unroll
-      for (int h = 0; h < NIH; ++h) {
-        const int r = lane + WS * h, rc = (r < NI) ? r : 0;
-        sv[h] = gsl[k * NI + rc]; zv[h] = gz[k * NI + rc]; gv[h] = st[D::gG + rc];
+        for (int h = 0; h < NIH; ++h) {
+          const int r = lane + WS * h, rc = (r < NI) ? r : 0;
+          sv[h] = gsl[k * NI + rc]; zv[h] = gz[k * NI + rc]; gv[h] = st[D::gG + rc];
+        }
+        hw0 = gx[k * NXA + 6]; hw1 = gx[k * NXA + 7]; hw2 = gx[k * NXA + 8];
       }
-      const double hw0 = gx[k * NXA + 6], hw1 = gx[k * NXA + 7], hw2 = gx[k * NXA + 8];
       double wa[NXA], wb[MERGE ? 1 : NXA], lam[NU];
       const int la = isA ? lane : 0;
       {
@@ -1750,6 +1765,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         }
       };
       if (!hasA) {                             // terminal node: no inputs; Lyapunov row inactive
+        if constexpr (PIPE) { CMPC_SYNC_WG(); break; }      // (dx_N is in LDS: the slack wave's last stage)
         double part = 0.0;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
@@ -1771,7 +1787,9 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         }
         duv = treg * dinv;
         if (isA) { gdu[k * NU + lane] = duv; L(D::oUK + lane) = duv; }
+        if constexpr (PIPE) { if (isA) xdu[(k & 1) * NU + lane] = duv; }
       }
+      if constexpr (PIPE) CMPC_SYNC_WG();      // du_k and dx_k stand in LDS; the slack wave is done with stage k - 1
       // dense rows: s_r = sum_c GH[r][c] z_c, z = (du, dx), one column per lane
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // s3: Lyapunov gradient . (du, dx)
 #pragma unroll
@@ -1780,10 +1798,10 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         const bool in = c < NZ;                // the row padding in the slab is never written
         const double z = (c < NU) ? duv : (in ? L(cur + c - NU) : 0.0);
         s0 += in ? gh[0][h] * z : 0.0; s1 += in ? gh[1][h] * z : 0.0; s2 += in ? gh[2][h] * z : 0.0;
-        s3 += in ? al[h] * z : 0.0;
+        if constexpr (!PIPE) s3 += in ? al[h] * z : 0.0;
       }
       // the four butterflies step together (same sums, same order as four reductions one after the other)
-#define CMPC_STEP4(M) do { s0 = bfly_sum<M>(s0); s1 = bfly_sum<M>(s1); s2 = bfly_sum<M>(s2); s3 = bfly_sum<M>(s3); } while (0)
+#define CMPC_STEP4(M) do { s0 = bfly_sum<M>(s0); s1 = bfly_sum<M>(s1); s2 = bfly_sum<M>(s2); if constexpr (!PIPE) s3 = bfly_sum<M>(s3); } while (0)
       CMPC_STEP4(32); CMPC_STEP4(16); CMPC_STEP4(8); CMPC_STEP4(4); CMPC_STEP4(2); CMPC_STEP4(1);
 #undef CMPC_STEP4
       if constexpr (NW != 1) {                 // the four sums cross the waves in one exchange
@@ -1796,7 +1814,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         s2 = L(D::oRED + 2) + R(D::oCOLD + 6); s3 = L(D::oRED + 3) + R(D::oCOLD + 7);
       }
       sync();
-      slack_dirs(s3);
+      if constexpr (!PIPE) slack_dirs(s3);
       CMPC_TICK(17);
       // dx+ = b + [B A] (du, dx)
       {
@@ -1828,7 +1846,72 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       { const int t = cur; cur = nxt; nxt = t; }
       CMPC_TICK(18);
     }
+    if constexpr (PIPE) {
+      CMPC_SYNC_WG();                          // the slack wave has reduced the step bounds
+      const double *xch = ldsR + 2 * D::LDS_DOUBLES;
+      ap = xch[6]; ad = xch[7];
+    } else {
+      ap = red_min(lap); ad = red_min(lad);
+    }
+  }
+
+  // PIPE, wave 1: slack / multiplier directions and the fraction-to-the-boundary bounds, stage by stage behind the
+  // chain wave (see vector_sweeps).  The stage's own data (slacks, multipliers, row values, Lyapunov gradient) are
+  // loaded before the barrier that releases du_k.
+  CMPC_DEV void slack_sweep(double mu, double &ap, double &ad) {
+    const double muf = rec[21];
+    constexpr int NIH = (NI + WS - 1) / WS;
+    const double tau = fmax(0.99, 1 - mu);
+    double lap = 1.0, lad = 1.0;
+    double *xch = ldsR + 2 * D::LDS_DOUBLES;
+    gsync();                                  // this wave's stores of the evaluation and of the last step
+    int cur = D::oXK, nxt = D::oXN1;          // the chain wave's dx_k / dx_{k+1} ping-pong
+    for (int k = 0; k <= N; ++k) {
+      const GArr st = stage(k);
+      const bool hasA = k < N;
+      const double gl = rec[(k < N) ? 24 + 19 * k + 17 : 22], gr = rec[(k < N) ? 24 + 19 * k + 18 : 23];
+      double al[NH], sv[NIH], zv[NIH], gv[NIH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) { const int c = lane + WS * h; al[h] = st[D::gAL + ((c < NZ) ? c : 0)]; }
+#pragma unroll
+      for (int h = 0; h < NIH; ++h) {
+        const int r = lane + WS * h, rc = (r < NI) ? r : 0;
+        sv[h] = gsl[k * NI + rc]; zv[h] = gz[k * NI + rc]; gv[h] = st[D::gG + rc];
+      }
+      const double hw0 = gx[k * NXA + 6], hw1 = gx[k * NXA + 7], hw2 = gx[k * NXA + 8];
+      CMPC_SYNC_WG();                          // du_k (this stage's parity slot) and dx_k are in LDS
+      const double *du = xch + XCH_DU + (k & 1) * NU;
+      double ldot = 0.0;                       // Lyapunov gradient . (du, dx); terminal node: . dx
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int c = lane + WS * h;
+        const bool in = c < NZ;
+        if (hasA) {
+          const double z = (c < NU) ? du[(c < NU) ? c : 0] : (in ? L(cur + c - NU) : 0.0);
+          ldot += in ? al[h] * z : 0.0;
+        } else if (c >= NU && c < NZ) ldot += al[h] * L(cur + c - NU);
+      }
+      ldot = wave_sum(ldot);
+#pragma unroll
+      for (int h = 0; h < NIH; ++h) {
+        const int r = lane + WS * h;
+        if (r < NI) {
+          const double sr_ = sv[h], zr = zv[h], gr_ = gv[h];
+          double ds = 0.0, dz = 0.0;
+          if (zr != 0.0) {
+            ds = -(gr_ + sr_) - jg_dot(r, ldot, &L(cur), du, hw0, hw1, hw2, gl, gr, muf);
+            dz = (mu - sr_ * zr - zr * ds) / sr_;
+            if (ds < 0) lap = fmin(lap, -tau * sr_ / ds);
+            if (dz < 0) lad = fmin(lad, -tau * zr / dz);
+          }
+          gds[k * NI + r] = ds; gdz[k * NI + r] = dz;
+        }
+      }
+      { const int t = cur; cur = nxt; nxt = t; }
+    }
     ap = red_min(lap); ad = red_min(lad);
+    if (lane == 0) { xch[6] = ap; xch[7] = ad; }
+    CMPC_SYNC_WG();
   }
 
   // (Jg d)[r] of one stage: dx, du in LDS, hw = x_k[6..8], g0/g1 = the stage's contact flags.  Every word any row type
@@ -1855,6 +1938,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     gsync();                                  // directions were written with a per-stage lane mapping
     // elementwise updates, four independent load groups in flight per pass
     constexpr int UF = 4;
+    const bool do_xu = !PIPE || wv == 0, do_sz = !PIPE || wv == 1;   // the pair shares the arrays out
+    if (do_xu)
     for (int e0 = NXA; e0 < (N + 1) * NXA; e0 += WS * UF) {
       double a[UF], b[UF], c[UF], d[UF];
 #pragma unroll
@@ -1868,6 +1953,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         if (e < (N + 1) * NXA) { gx[e] = a[q] + ap * b[q]; glam[e] = c[q] + ap * (d[q] - c[q]); }
       }
     }
+    if (do_xu)
     for (int e0 = 0; e0 < N * NU; e0 += WS * UF) {
       double a[UF], b[UF];
 #pragma unroll
@@ -1881,6 +1967,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         if (e < N * NU) gu[e] = a[q] + ap * b[q];
       }
     }
+    if (do_sz)
     for (int e0 = 0; e0 < (N + 1) * NI; e0 += WS * UF) {
       double zq[UF], sq[UF], dsq[UF], dzq[UF];
 #pragma unroll
@@ -2123,16 +2210,9 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       }
       double ap, ad;
       if constexpr (PIPE) {
-        double *xch = ldsR + 2 * D::LDS_DOUBLES;
-        if (wv == 0) {
-          vector_sweeps(mu, mu - mu_sweep, ap, ad);
-          CMPC_TICK(6);
-          apply_step(mu, ap, ad);
-          CMPC_TICK(7);
-          if (lane == 0) xch[6] = ap;
-        }
-        pair_sync();                            // the new iterate (global) and the step length reach the other wave
-        ap = xch[6];
+        vector_sweeps(mu, mu - mu_sweep, ap, ad);   // wave 0: du, dx, lam; wave 1: ds, dz, step bounds
+        apply_step(mu, ap, ad);                     // wave 0: x, lam, u; wave 1: s, z
+        pair_sync();                                // the new iterate (global) reaches the other wave
         n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
       } else {
         vector_sweeps(mu, mu - mu_sweep, ap, ad);
