@@ -1537,7 +1537,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         }
         }
         const double a = (b0 + b1) + (b2 + b3);
-        L(D::oXN1 + lane) = R(D::oPC + lane) + a;       // v0 = p0_{k+1} + P_{k+1} b
+        // v0 = p0_{k+1} + P_{k+1} b  (PIPE: p_{k+1} is still being formed by the other wave, which adds it: pair_vectors)
+        if constexpr (PIPE) L(D::oXN1 + lane) = a; else L(D::oXN1 + lane) = R(D::oPC + lane) + a;
         st[D::gB + lane] = L(D::oBV + lane);
       }
       sync();                            // the T tile of add_GtPG aliases BV and the other stage vectors
@@ -1548,7 +1549,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       CMPC_RELANE(lane); CMPC_OPAQUE(lane);
       if (!factor_stage(k)) return false;
       CMPC_TICK(8);
-      backward_vectors(k);
+      if constexpr (!PIPE) backward_vectors(k);    // (PIPE: the vector recursion follows one step behind, on the other wave)
       CMPC_TICK(5);
     } else {
       if (lane < NXA) {                      // terminal cost-to-go gradient p_N = h_N (x part), split in mu
@@ -1571,6 +1572,18 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     return true;
   }
 
+  // PIPE, wave 1: the backward vector recursion of stage k < N, one step behind the factorisation.  The matrix recursion
+  // (P_k) does not depend on it, so the Riccati wave goes straight on to stage k - 1; L, Ls (packed M), the gradient
+  // parts and P_{k+1} b (left in XN1 by the Riccati wave) stand in stage k's image until this wave evaluates stage
+  // k - 2 into it, which it does right after this.  Same expressions as the single wave's riccati_stage.
+  CMPC_DEV void pair_vectors(int k) {
+    CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+    build_list(&L(D::oGH), L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
+    if (lane < NXA) L(D::oXN1 + lane) = R(D::oPC + lane) + L(D::oXN1 + lane);
+    sync();
+    backward_vectors(k);
+  }
+
   // ---------------------------------------------------------------------------------------
   // Matrix sweep: evaluate + factorise every stage backwards.  Returns false on wrong inertia.
   // Accumulates the KKT error measures (per lane; reduced by the caller).
@@ -1591,20 +1604,22 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       }
       return true;
     } else {
-      // step j: wave 1 evaluates stage N - j into image (N - j) & 1 while wave 0 takes stage N - j + 1 out of the other
-      // image; one workgroup barrier per step.  A failed factorisation is published in the exchange words behind the
-      // two images and seen by both waves after the barrier of its step.
+      // step j: wave 0 takes stage N - j + 1 (P b, G'PG, factorisation, factor store) out of image (N - j + 1) & 1; wave 1
+      // first runs the vector recursion of stage N - j + 2, whose factors wave 0 left in image (N - j) & 1 the step
+      // before, then evaluates stage N - j into that image.  One workgroup barrier per step.  A failed factorisation is
+      // published in the exchange words behind the two images and seen by both waves after the barrier of its step.
       // (the verdict of step j sits in word 8 + (j & 1): wave 0 may be a step ahead of wave 1's read of the last one)
       double *xch = ldsR + 2 * D::LDS_DOUBLES;
       if (lane == 0 && wv == 0) { xch[8] = 0.0; xch[9] = 0.0; }
       CMPC_SYNC_WG();
-      for (int j = 0; j <= N + 1; ++j) {
+      for (int j = 0; j <= N + 2; ++j) {
         if (wv == 1) {
-          const int k = N - j;
+          const int kv = N - j + 2, k = N - j;
+          if (kv >= 0 && kv < N) { image(kv); pair_vectors(kv); }
           const double wz = sp.w_cz_const * 0.5 * ez + sp.w_cz_const * 0.5;
           ez *= e1;
           if (k >= 0) { image(k); eval_stage(k, mu, reg, wz, x0n2, er, init); }
-        } else if (j >= 1) {
+        } else if (j >= 1 && j <= N + 1) {
           const int k = N - j + 1;
           image(k);
           if (!riccati_stage(k) && lane == 0) xch[8 + (j & 1)] = 1.0;
@@ -1614,6 +1629,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         if (failed) { image(0); CMPC_SYNC_WG(); return false; }
       }
       image(0);
+      pair_sync();                             // the vector recursion's l, p (global) reach the forward sweep's wave
       return true;
     }
   }
