@@ -1566,22 +1566,26 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       sync();
     }
     CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-    store_factors(k);
+    if constexpr (!PIPE) store_factors(k);     // (PIPE: the other wave copies the image out, after its vector recursion)
     sync();
     CMPC_TICK(4);
     return true;
   }
 
-  // PIPE, wave 1: the backward vector recursion of stage k < N, one step behind the factorisation.  The matrix recursion
+  // PIPE, wave 1: the backward vector recursion of stage k < N and the factor store, one step behind the factorisation.  The matrix recursion
   // (P_k) does not depend on it, so the Riccati wave goes straight on to stage k - 1; L, Ls (packed M), the gradient
   // parts and P_{k+1} b (left in XN1 by the Riccati wave) stand in stage k's image until this wave evaluates stage
   // k - 2 into it, which it does right after this.  Same expressions as the single wave's riccati_stage.
   CMPC_DEV void pair_vectors(int k) {
     CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-    build_list(&L(D::oGH), L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
-    if (lane < NXA) L(D::oXN1 + lane) = R(D::oPC + lane) + L(D::oXN1 + lane);
+    if (k < N) {
+      build_list(&L(D::oGH), L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
+      if (lane < NXA) L(D::oXN1 + lane) = R(D::oPC + lane) + L(D::oXN1 + lane);
+      sync();
+      backward_vectors(k);
+    }
+    store_factors(k);                          // the factor image of stage k (terminal node: P_N) to the slab
     sync();
-    backward_vectors(k);
   }
 
   // ---------------------------------------------------------------------------------------
@@ -1615,7 +1619,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       for (int j = 0; j <= N + 2; ++j) {
         if (wv == 1) {
           const int kv = N - j + 2, k = N - j;
-          if (kv >= 0 && kv < N) { image(kv); pair_vectors(kv); }
+          if (kv >= 0 && kv <= N) { image(kv); pair_vectors(kv); }
           const double wz = sp.w_cz_const * 0.5 * ez + sp.w_cz_const * 0.5;
           ez *= e1;
           if (k >= 0) { image(k); eval_stage(k, mu, reg, wz, x0n2, er, init); }
