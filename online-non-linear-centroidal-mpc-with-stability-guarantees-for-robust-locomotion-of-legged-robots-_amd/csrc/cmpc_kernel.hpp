@@ -1501,8 +1501,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
     }
     if (k < N) {
-      // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG
-      if (lane < NXA) {
+      // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG  (PIPE: P b is the other wave's, pair_vectors)
+      if (!PIPE && lane < NXA) {
         const double *bv = &L(D::oBV);
         double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
         if constexpr (D::P_PACKED) {
@@ -1537,8 +1537,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         }
         }
         const double a = (b0 + b1) + (b2 + b3);
-        // v0 = p0_{k+1} + P_{k+1} b  (PIPE: p_{k+1} is still being formed by the other wave, which adds it: pair_vectors)
-        if constexpr (PIPE) L(D::oXN1 + lane) = a; else L(D::oXN1 + lane) = R(D::oPC + lane) + a;
+        L(D::oXN1 + lane) = R(D::oPC + lane) + a;       // v0 = p0_{k+1} + P_{k+1} b
         st[D::gB + lane] = L(D::oBV + lane);
       }
       sync();                            // the T tile of add_GtPG aliases BV and the other stage vectors
@@ -1580,11 +1579,45 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     CMPC_RELANE(lane); CMPC_OPAQUE(lane);
     if (k < N) {
       build_list(&L(D::oGH), L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
-      if (lane < NXA) L(D::oXN1 + lane) = R(D::oPC + lane) + L(D::oXN1 + lane);
+      if (lane < NXA) L(D::oXN1 + lane) = R(D::oPC + lane) + L(D::oXN1 + lane);   // v0 = p0_{k+1} + P_{k+1} b
       sync();
       backward_vectors(k);
     }
     store_factors(k);                          // the factor image of stage k (terminal node: P_N) to the slab
+    if (k >= 1) {
+      // P_k b_{k-1} for the stage the Riccati wave is working on: P_k from this image's packed M (rows NU + i hold
+      // [Ls row i | P_k row i up to the diagonal]; the same words the single wave reads from its P copy), b from the other
+      // image, where stage k - 1 was evaluated; the product is left in that image's XN1 for this wave's next step.
+      static_assert(!PIPE || (D::P_PACKED && NXA == 28), "three batches of ten");
+      double *other = ldsR + ((k - 1) & 1) * D::LDS_DOUBLES;
+      if (lane < NXA) {
+        const double *bv = other + D::oBV;
+        double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        double pr[30];
+        {
+          const int tl = tri(NU + lane) + NU;
+#pragma unroll
+          for (int q0 = 0; q0 < 30; q0 += 10) {
+            cmpc_lds_word pa[10];
+            double v[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+              const int qq = (q0 + q < NXA) ? q0 + q : NXA - 1;
+              pa[q] = cmpc_lds_word_at(&L(D::oM), (qq <= lane) ? tl + qq : tri(NU + qq) + NU + lane);
+            }
+            lds_read_gather10(v, pa);
+#pragma unroll
+            for (int q = 0; q < 10; ++q) pr[q0 + q] = v[q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NXA; q += 4) {
+          b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
+        }
+        other[D::oXN1 + lane] = (b0 + b1) + (b2 + b3);
+        stage(k - 1)[D::gB + lane] = bv[lane];
+      }
+    }
     sync();
   }
 
