@@ -230,7 +230,8 @@ struct cmpc_handle {
   cmpc_spec spec;
   int device = 0;
   int grid = 0;
-  int pair_grid = 0;                                // resident grid of the pipelined pair kernel (nv = 4), 0 = never used
+  int pair_grid = 0;                                // resident grid of the pipelined pair kernel (nv = 4)
+  int pair_max_batch = 0;                           // largest batch that goes to the pair kernel, 0 = never used
   int num_cu = 0;
   size_t slab_doubles = 0;
   double *scratch = nullptr;
@@ -334,8 +335,12 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
     int n = (int)((160 * 1024) / alloc);
     if (n > 2) n = 2;
     h->pair_grid = h->num_cu * (n < 1 ? 1 : n);
+    // Up to four rounds of pairs the pair kernel is the faster one (an instance-iteration takes 0.4 ms in a pair against
+    // 0.65 - 1.2 ms in one of two to six waves of a CU, and a short queue is mostly its longest instance): measured
+    // crossover between 2048 and 2560 instances on 256 CUs (profiles/r04h_pair_crossover.txt)
+    h->pair_max_batch = 4 * h->pair_grid;
     if (const char *e = getenv("CMPC_PAIR")) {         // developer knob: 0 = never, 1 = always (A/B measurements)
-      if (atoi(e) == 0) h->pair_grid = 0; else h->pair_grid = 1 << 30;
+      h->pair_max_batch = (atoi(e) == 0) ? 0 : 1 << 30;
     }
   }
   if (const char *e = getenv("CMPC_WG_PER_CU")) {      // developer knob: fewer resident workgroups per CU (occupancy studies)
@@ -410,8 +415,8 @@ int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, cons
   hipLaunchKernelGGL(cmpc_order_score_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->spec.N, omega, h->spec.cz_max, params, state_in, nstate,
                      mu_word, h->order + B, h->ticket);
   hipLaunchKernelGGL(cmpc_order_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->order + B, h->order, h->ticket);
-  if (h->spec.nv == 4 && B <= h->pair_grid)          // the batch does not fill the GPU: two waves per instance
-    hipLaunchKernelGGL((cmpc_solve_pair_kernel<4>), dim3(grid), dim3(128), 0, st, ka, h->ticket, h->order);
+  if (h->spec.nv == 4 && B <= h->pair_max_batch)     // the batch does not fill the GPU for long: two waves per instance
+    hipLaunchKernelGGL((cmpc_solve_pair_kernel<4>), dim3(B < h->pair_grid ? B : h->pair_grid), dim3(128), 0, st, ka, h->ticket, h->order);
   else if (h->spec.nv == 4)
     hipLaunchKernelGGL((cmpc_solve_kernel<4, 1>), dim3(grid), dim3(64), 0, st, ka, h->ticket, h->order);
   else
