@@ -17,7 +17,7 @@ def _newer(target, sources):
 def build_hip(force=False, verbose=False):
     src = os.path.join(PKG, "csrc", "cmpc_hip.hip")
     wbc = os.path.join(PKG, "csrc", "wbc_qp.hip")          # batched whole-body QP (include/cmpc_wbc.h), same library
-    deps = [src, wbc, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"), os.path.join(PKG, "csrc", "cmpc_order_fit.h"),
+    deps = [src, wbc, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"), os.path.join(PKG, "csrc", "cmpc_wave.hpp"), os.path.join(PKG, "csrc", "cmpc_order_fit.h"),
             os.path.join(ROOT, "include", "cmpc.h"), os.path.join(ROOT, "include", "cmpc_wbc.h")]
     out = os.path.join(PKG, "libcmpc_amd.so")
     if force or _newer(out, deps):
@@ -31,7 +31,7 @@ def build_hip(force=False, verbose=False):
 def build_hip_profile(force=False):
     """Diagnostic variant with in-kernel phase timers (tools/ only; never loaded by the package)."""
     src = os.path.join(PKG, "csrc", "cmpc_hip.hip")
-    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"),
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"), os.path.join(PKG, "csrc", "cmpc_wave.hpp"),
             os.path.join(ROOT, "include", "cmpc.h")]
     out = os.path.join(ROOT, "tools", "libcmpc_amd_prof.so")
     if force or _newer(out, deps):
@@ -52,7 +52,7 @@ def build_oracle(force=False):
 def build_emu(force=False):
     src = os.path.join(ROOT, "tests", "emu", "cmpc_emu.cpp")
     out = os.path.join(ROOT, "tests", "emu", "libcmpc_emu.so")
-    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"),
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"), os.path.join(PKG, "csrc", "cmpc_wave.hpp"),
             os.path.join(ROOT, "include", "cmpc.h")]
     if force or _newer(out, deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", out, src])
@@ -63,7 +63,7 @@ def build_device_unit(force=False):
     """GPU-tier unit harness for the device-only primitives (tests/gpu_unit): never loaded by the package."""
     src = os.path.join(ROOT, "tests", "gpu_unit", "cmpc_device_unit.hip")
     out = os.path.join(ROOT, "tests", "gpu_unit", "libcmpc_device_unit.so")
-    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp")]
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"), os.path.join(PKG, "csrc", "cmpc_wave.hpp")]
     if force or _newer(out, deps):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out, src])
     return out

@@ -8,10 +8,12 @@
 //   * primal-dual interior point on the 42-variable problem, the same monotone barrier schedule and
 //     fraction-to-the-boundary rule as the centroidal MPC solver;
 //   * every Newton step is one L D L' factorisation of the 48 x 48 quasi-definite KKT matrix
-//         [ Hq                                 M_b'  ]      in LDS, lane i owns row i of the lower triangle (row stride
-//         [      1e-6 I + A' diag(z/s) A      -Jc_b  ]      49: column reads across lanes are conflict free); column j
-//         [ M_b        -Jc_b'                   0    ]      is read by every lane at wave-uniform addresses
-//     followed by two triangular solves against the factor (v_readlane broadcasts of the running solution).
+//         [ Hq                                 M_b'  ]      in REGISTERS: lane i holds row i of the lower triangle (48
+//         [      1e-6 I + A' diag(z/s) A      -Jc_b  ]      doubles, statically indexed: the pivot loops are fully
+//         [ M_b        -Jc_b'                   0    ]      unrolled); element (k, j) of the pivot column reaches the
+//     other lanes by v_readlane.  Round 3 kept the matrix in LDS (a read-modify-write per element and update, 48.9 KB per
+//     instance -> three instances per CU); now LDS holds the problem data and the packed factor only (20.7 KB -> seven).
+//     Forward substitution from the registers; the backward one needs the transposed factor and reads it from LDS.
 // Failure (status 1 / 2: iteration cap, wrong-inertia pivot, non-finite KKT error) returns zeros in tau, qdd and f_c, as
 // the reference's QPSolver.solve does when OSQP fails (code/utils.py:85-92).
 // The problem data of an instance (Hq, M_b, Jc_b: 8.4 KB) is staged in LDS once; per iteration nothing touches HBM.
@@ -21,6 +23,7 @@
 #include <string>
 
 #include "../../include/cmpc_wbc.h"
+#include "cmpc_wave.hpp"
 
 namespace {
 
@@ -44,24 +47,20 @@ constexpr int oZ = oS + NI;                              // z (16)
 constexpr int oSIG = oZ + NI;                            // z / s (16)
 constexpr int oW = oSIG + NI;                            // mu / s + sigma * (A x + s) (16)
 constexpr int oRHS = oW + NI;                            // right-hand side / solution (48)
-constexpr int LS = NK + 1;
-constexpr int oL = oRHS + NK;                            // L (48 x 49), D on the diagonal
-constexpr int oK0 = oL + NK * LS;                        // constant part of the KKT matrix, lower triangle (48 x 49)
-constexpr int LDS_DOUBLES = oK0 + NK * LS;
+constexpr int oL = oRHS + NK;                            // strictly lower part of L, packed: row i at tri(i)
+constexpr int LDS_DOUBLES = oL + NK * (NK + 1) / 2;
+__device__ __forceinline__ constexpr int tri(int i) { return i * (i + 1) / 2; }
 
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // one wave per workgroup
-__device__ __forceinline__ double wave_max(double v) {
-  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
-  return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-  for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m));
-  return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
-}
+// wave-wide reductions: six butterfly steps through v_permlane*_swap / DPP (cmpc_wave.hpp), no LDS round trip
+#define WBC_BFLY(op)                                                                                             \
+  { double a, b;                                                                                                 \
+    cmpc_pair_of<32>(v, a, b); v = op; cmpc_pair_of<16>(v, a, b); v = op; cmpc_pair_of<8>(v, a, b); v = op;      \
+    cmpc_pair_of<4>(v, a, b); v = op; cmpc_pair_of<2>(v, a, b); v = op; cmpc_pair_of<1>(v, a, b); v = op; }
+__device__ __forceinline__ double wave_max(double v) { WBC_BFLY(fmax(a, b)) return v; }
+__device__ __forceinline__ double wave_min(double v) { WBC_BFLY(fmin(a, b)) return v; }
+__device__ __forceinline__ double wave_sum(double v) { WBC_BFLY(a + b) return v; }
+#undef WBC_BFLY
 __device__ __forceinline__ double bcast(double v, int src) {
   union { double d; int i[2]; } u; u.d = v;
   u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
@@ -79,7 +78,7 @@ __device__ __forceinline__ double wrench_entry(int r, int c, double d, double mu
   return 0.0;
 }
 
-__global__ void __launch_bounds__(64) wbc_qp_kernel(int B, const double *__restrict__ Hq, const double *__restrict__ Fq,
+__global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__restrict__ Hq, const double *__restrict__ Fq,
                                                     const double *__restrict__ M, const double *__restrict__ hvec,
                                                     const double *__restrict__ Jc, double dfoot, double muf, double tol,
                                                     int max_iter, double *__restrict__ tau, double *__restrict__ qdd,
@@ -101,40 +100,29 @@ __global__ void __launch_bounds__(64) wbc_qp_kernel(int B, const double *__restr
     if (lane < NB) L[oNU + lane] = 0.0;
     if (lane < NI) { L[oS + lane] = 1.0; L[oZ + lane] = mu; }
     lds_fence();
-    // constant part of this lane's row of the KKT matrix (lower triangle, columns 0 .. lane; zeros right of it)
-    if (lane < NK) {
-      for (int j = 0; j < NK; ++j) {
-        double v = 0.0;
-        if (j <= lane) {
-          if (lane < ND) v = L[oH + lane * HS + j];
-          else if (lane < NX) v = (j == lane) ? F_REG : 0.0;
-          else {
-            const int e = lane - NX;
-            v = (j < ND) ? L[oMB + e * HS + j] : ((j < NX) ? -L[oJB + (j - ND) * 7 + e] : 0.0);
-          }
-        }
-        L[oK0 + lane * LS + j] = v;
-      }
-    }
-    lds_fence();
     int st = 1, it = 0;
     for (it = 0; it <= max_iter; ++it) {
+      // (the ln id is made opaque in every iteration, and again between its phases: otherwise the ~300 ln-against-
+      // constant predicates and clamped addresses of the unrolled loops below are hoisted out of the iteration loop and
+      // held -- spilled -- across it)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
       // ---- residuals.  lanes 0..41: dual residual of x_i; lanes 42..47: equality rows; lanes 0..15 also: A x + s
       double hx = 0.0, rd = 0.0, rp = 0.0, rg = 0.0, aiz = 0.0;
-      if (lane < ND) {
+      if (ln < ND) {
 #pragma unroll
-        for (int j = 0; j < ND; ++j) hx += L[oH + lane * HS + j] * L[oX + j];
+        for (int j = 0; j < ND; ++j) hx += L[oH + ln * HS + j] * L[oX + j];
 #pragma unroll
-        for (int e = 0; e < NB; ++e) rd += L[oMB + e * HS + lane] * L[oNU + e];
-      } else if (lane < NX) {
-        const int c = lane - ND, foot = c / 6, comp = c % 6;
-        hx = F_REG * L[oX + lane];
+        for (int e = 0; e < NB; ++e) rd += L[oMB + e * HS + ln] * L[oNU + e];
+      } else if (ln < NX) {
+        const int c = ln - ND, foot = c / 6, comp = c % 6;
+        hx = F_REG * L[oX + ln];
 #pragma unroll
         for (int e = 0; e < NB; ++e) rd -= L[oJB + c * 7 + e] * L[oNU + e];
 #pragma unroll
         for (int r = 0; r < 8; ++r) aiz += wrench_entry(r, comp, dfoot, muf) * L[oZ + 8 * foot + r];
-      } else if (lane < NK) {
-        const int e = lane - NX;
+      } else if (ln < NK) {
+        const int e = ln - NX;
 #pragma unroll
         for (int j = 0; j < ND; ++j) rp += L[oMB + e * HS + j] * L[oX + j];
 #pragma unroll
@@ -142,20 +130,20 @@ __global__ void __launch_bounds__(64) wbc_qp_kernel(int B, const double *__restr
         rp += L[oHB + e];                                  // A_e x - b_e with b_e = -h_b
       }
       double gx = 0.0;                                     // (A_i x)_r for lanes 0..15
-      if (lane < NI) {
-        const int foot = lane / 8, r = lane % 8;
+      if (ln < NI) {
+        const int foot = ln / 8, r = ln % 8;
 #pragma unroll
         for (int c = 0; c < 6; ++c) gx += wrench_entry(r, c, dfoot, muf) * L[oX + ND + 6 * foot + c];
-        rg = gx + L[oS + lane];
+        rg = gx + L[oS + ln];
       }
-      const double grad = (lane < NX) ? hx + L[oF + lane] : 0.0;      // H x + F
-      rd = (lane < NX) ? grad + rd + aiz : 0.0;
-      const double sl = (lane < NI) ? L[oS + lane] : 1.0, zl = (lane < NI) ? L[oZ + lane] : 0.0;
-      const double sum_mult = wave_sum(((lane < NB) ? fabs(L[oNU + lane]) : 0.0) + ((lane < NI) ? fabs(zl) : 0.0));
+      const double grad = (ln < NX) ? hx + L[oF + ln] : 0.0;      // H x + F
+      rd = (ln < NX) ? grad + rd + aiz : 0.0;
+      const double sl = (ln < NI) ? L[oS + ln] : 1.0, zl = (ln < NI) ? L[oZ + ln] : 0.0;
+      const double sum_mult = wave_sum(((ln < NB) ? fabs(L[oNU + ln]) : 0.0) + ((ln < NI) ? fabs(zl) : 0.0));
       const double sd = fmax(100.0, sum_mult / (NB + NI)) / 100.0;
       const double e_d = wave_max(fabs(rd)) / sd, e_p = wave_max(fmax(fabs(rp), fabs(rg)));
-      const double e_c = wave_max((lane < NI) ? fabs(sl * zl) : 0.0) / sd;
-      const double e_cmu = wave_max((lane < NI) ? fabs(sl * zl - mu) : 0.0) / sd;
+      const double e_c = wave_max((ln < NI) ? fabs(sl * zl) : 0.0) / sd;
+      const double e_cmu = wave_max((ln < NI) ? fabs(sl * zl - mu) : 0.0) / sd;
       const double kkt = fmax(fmax(e_d, e_p), e_c);
       // (fmax drops NaNs: a NaN residual must be looked for, or a NaN input "converges" with NaN outputs)
       const double nonfinite = wave_max((isfinite(rd) && isfinite(rp) && isfinite(rg) && isfinite(sl * zl)) ? 0.0 : 1.0);
@@ -164,75 +152,106 @@ __global__ void __launch_bounds__(64) wbc_qp_kernel(int B, const double *__restr
       if (it == max_iter) break;
       while (mu > tol / 10 && fmax(fmax(e_d, e_p), e_cmu) < 10 * mu) mu = fmax(tol / 10, fmin(0.1 * mu, mu * sqrt(mu)));
       // ---- barrier weights, right-hand side
-      if (lane < NI) {
+      if (ln < NI) {
         const double sg = zl / sl;
-        L[oSIG + lane] = sg;
-        L[oW + lane] = mu / sl + sg * rg;
+        L[oSIG + ln] = sg;
+        L[oW + ln] = mu / sl + sg * rg;
       }
       lds_fence();
       double rhs = 0.0;
-      if (lane < ND) rhs = -grad;
-      else if (lane < NX) {
-        const int c = lane - ND, foot = c / 6, comp = c % 6;
+      if (ln < ND) rhs = -grad;
+      else if (ln < NX) {
+        const int c = ln - ND, foot = c / 6, comp = c % 6;
         double aw = 0.0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) aw += wrench_entry(r, comp, dfoot, muf) * L[oW + 8 * foot + r];
         rhs = -grad - aw;
-      } else if (lane < NK) rhs = -rp;
-      // ---- the KKT matrix of this step (lower triangle, lane i owns row i): constant part + A' diag(sigma) A in the
-      // wrench block of the row's foot
-      double *A = &L[oL];
-      if (lane < NK) {
-        for (int j = 0; j <= lane; ++j) {
-          double v = L[oK0 + lane * LS + j];
-          if (lane >= ND && lane < NX && j >= ND) {
-            const int c = lane - ND, foot = c / 6, comp = c % 6, cj = j - ND - 6 * foot;
-            if (cj >= 0 && cj <= comp)
-              for (int r = 0; r < 8; ++r)
-                v += L[oSIG + 8 * foot + r] * wrench_entry(r, comp, dfoot, muf) * wrench_entry(r, cj, dfoot, muf);
-          }
-          A[lane * LS + j] = v;
-        }
-      }
-      lds_fence();
-      // ---- L D L' in place (no pivoting: quasi-definite).  Step j: l_ij = a_ij / d_j, a_ik -= l_ij a_kj (j < k <= i)
-      bool ok = true;
-#pragma unroll 1
+      } else if (ln < NK) rhs = -rp;
+      // ---- the KKT matrix of this step, row `ln` of the lower triangle in registers (words right of the diagonal are
+      // never used): Hq / 1e-6 I + A' diag(sigma) A in the wrench block of the row's foot / [M_b, -Jc_b'].  Every word
+      // any row type needs is read unconditionally at a clamped address, then the row type selects.
+      asm volatile("" : "+v"(ln));
+      // this ln's place in the KKT matrix: a qdd row, a contact-wrench row or a floating-base row
+      const bool isq = ln < ND, isf = ln >= ND && ln < NX, ise = ln >= NX && ln < NK;
+      const int rowq = isq ? ln : ND - 1, rowe = ise ? ln - NX : 0;
+      const int cf = isf ? ln - ND : 0, foot_l = cf / 6, comp_l = cf % 6;
+      double wl[8];                                        // this row's column of the wrench rows
+#pragma unroll
+      for (int r = 0; r < 8; ++r) wl[r] = wrench_entry(r, comp_l, dfoot, muf);
+      double a[NK];
+#pragma unroll
       for (int j = 0; j < NK; ++j) {
-        const double dj = A[j * LS + j];
-        ok = ok && ((j < NX) ? (dj > 0.0) : (dj < 0.0));
-        const bool mine = lane > j && lane < NK;
-        const double lij = mine ? A[lane * LS + j] / dj : 0.0;
-#pragma unroll 4
-        for (int k = j + 1; k < NK; ++k) {
-          const double akj = A[k * LS + j];                // column j, still unscaled
-          if (mine && lane >= k) A[lane * LS + k] -= lij * akj;
+        double v = 0.0;
+        if (j < ND) {
+          const double hv = L[oH + rowq * HS + j], mv = L[oMB + rowe * HS + j];
+          v = isq ? hv : (ise ? mv : 0.0);
+        } else if (j < NX) {
+          const int cj = (j - ND) % 6, fj = (j - ND) / 6;
+          const double v0 = (ln == j) ? F_REG : 0.0;
+          double acc = v0;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) acc += L[oSIG + 8 * fj + r] * wl[r] * wrench_entry(r, cj, dfoot, muf);
+          const double jv = -L[oJB + (j - ND) * 7 + rowe];
+          v = isf ? ((foot_l == fj && cj <= comp_l) ? acc : v0) : (ise ? jv : 0.0);
         }
-        lds_fence();
-        if (mine) A[lane * LS + j] = lij;
-        lds_fence();
+        a[j] = v;
+        if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);   // (keeps the batch of LDS reads in flight to eight columns)
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- L D L' in registers (no pivoting: quasi-definite).  Step j: l_ij = a_ij / d_j, a_ik -= l_ij a_kj (j < k <= i);
+      // a_kj is ln k's word j.  Lanes <= j run along with l_ij = 0, words right of a ln's diagonal take garbage.
+      bool ok = true;
+      double dl = 1.0;                                     // this ln's pivot
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        const double dj = bcast(a[j], j);
+        ok = ok && ((j < NX) ? (dj > 0.0) : (dj < 0.0));
+        dl = (ln == j) ? dj : dl;
+        const double lij = (ln > j) ? a[j] / dj : 0.0;
+#pragma unroll
+        for (int k = j + 1; k < NK; ++k) {
+          a[k] -= lij * bcast(a[j], k);                      // column j, still unscaled
+          if ((k - j) % 8 == 0) __builtin_amdgcn_sched_barrier(0);   // (the broadcast words are scalars: no more than eight pairs in flight)
+        }
+        a[j] = (ln > j) ? lij : a[j];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       if (!ok) { st = 2; break; }
-      // ---- forward substitution L y = rhs, D, backward substitution L' x = y
+      // ---- forward substitution L y = rhs out of the registers, D, then the factor's strictly lower part to LDS (packed
+      // rows) for the backward substitution L' x = y, which reads it by columns
+      asm volatile("" : "+v"(ln));
       double y = rhs;
-#pragma unroll 1
+#pragma unroll
       for (int j = 0; j < NK; ++j) {
         const double yj = bcast(y, j);
-        if (lane > j && lane < NK) y -= A[lane * LS + j] * yj;
+        if (ln > j) y -= a[j] * yj;
       }
-      if (lane < NK) y /= A[lane * LS + lane];
-#pragma unroll 1
-      for (int j = NK - 1; j >= 0; --j) {
-        const double xj = bcast(y, j);
-        if (lane < j) y -= A[j * LS + lane] * xj;
+      y /= dl;
+      if (ln < NK) {
+        const int tl = tri(ln);
+#pragma unroll
+        for (int j = 0; j < NK - 1; ++j)
+          if (j < ln) L[oL + tl + j] = a[j];
+      }
+      lds_fence();
+      {
+        double col[NK];                                    // column `ln` of L below the diagonal, one batch of reads
+#pragma unroll
+        for (int j = 1; j < NK; ++j) col[j] = L[oL + tri(j) + ((ln < j) ? ln : 0)];
+#pragma unroll
+        for (int j = NK - 1; j >= 1; --j) {
+          const double xj = bcast(y, j);
+          if (ln < j) y -= col[j] * xj;
+        }
       }
       // y: lanes 0..41 dx, lanes 42..47 the new equality multipliers
-      if (lane < NK) L[oRHS + lane] = y;
+      if (ln < NK) L[oRHS + ln] = y;
       lds_fence();
       // ---- slack / multiplier directions, fraction to the boundary
       double ds = 0.0, dz = 0.0, ap = 1.0, ad = 1.0;
-      if (lane < NI) {
-        const int foot = lane / 8, r = lane % 8;
+      if (ln < NI) {
+        const int foot = ln / 8, r = ln % 8;
         double adx = 0.0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) adx += wrench_entry(r, c, dfoot, muf) * L[oRHS + ND + 6 * foot + c];
@@ -243,9 +262,9 @@ __global__ void __launch_bounds__(64) wbc_qp_kernel(int B, const double *__restr
         if (dz < 0.0) ad = fmin(ad, -tf * zl / dz);
       }
       ap = wave_min(ap); ad = wave_min(ad);
-      if (lane < NX) L[oX + lane] += ap * y;
-      else if (lane < NK) L[oNU + lane - NX] += ap * (y - L[oNU + lane - NX]);
-      if (lane < NI) { L[oS + lane] = sl + ap * ds; L[oZ + lane] = zl + ad * dz; }
+      if (ln < NX) L[oX + ln] += ap * y;
+      else if (ln < NK) L[oNU + ln - NX] += ap * (y - L[oNU + ln - NX]);
+      if (ln < NI) { L[oS + ln] = sl + ap * ds; L[oZ + ln] = zl + ad * dz; }
       lds_fence();
     }
     // ---- outputs: qdd, f_c, tau[6:] = M_a qdd + h_a - Jc_a' f_c  (tau[0:6] = 0)
