@@ -470,8 +470,8 @@ def main():
                             "algorithmic_bytes_per_qp": bytes_q,
                             "hbm_frac": bytes_q * Bq / (ms_q * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "note": "code/inverse_dynamics.py:92-134 for 65536 robots (1024 distinct synthetic instances, "
-                                    "30 dofs, double support), wbc_qp_kernel, KKT error <= 1e-9; latency bound like the MPC "
-                                    "kernel (one wave per QP, 48 serial pivots per Newton step)"}
+                                    "30 dofs, double support), wbc_qp_kernel, KKT error <= 1e-9; one wave per QP, L D L' of the "
+                                    "48 x 48 KKT matrix in registers (48 serial pivots per Newton step), seven QPs per CU"}
         if not args.no_cpu_baseline:
             from oracle import wbc_qp_oracle as wq        # the numpy oracle of the QP, timed on one core
             t0 = time.perf_counter()
