@@ -100,6 +100,53 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__re
     if (lane < NB) L[oNU + lane] = 0.0;
     if (lane < NI) { L[oS + lane] = 1.0; L[oZ + lane] = mu; }
     lds_fence();
+    // ---- the part of the factorisation that does not change from step to step.  Only the wrench block of the KKT
+    // matrix carries barrier terms (columns ND .. NX-1 of rows ND .. NX-1); the first ND pivots run over Hq alone, so the
+    // rows' first ND words of L and the Schur complement they leave in columns ND .. NK-1 are computed ONCE per instance:
+    // ac[0 .. ND) = row `lane` of L in the qdd columns, ac[ND .. NK) = constant part of the trailing 18 x 18 block.
+    // Per Newton step: 153 multiply-adds of the factorisation instead of 1128.
+    double ac[NK], dlc = 1.0;
+    bool ok0 = true;
+    {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const bool isq = ln < ND, isf = ln >= ND && ln < NX, ise = ln >= NX && ln < NK;
+      const int rowq = isq ? ln : ND - 1, rowe = ise ? ln - NX : 0;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        double v = 0.0;
+        if (j < ND) {
+          const double hv = L[oH + rowq * HS + j], mv = L[oMB + rowe * HS + j];
+          v = isq ? hv : (ise ? mv : 0.0);
+        } else if (j < NX) {
+          const double jv = -L[oJB + (j - ND) * 7 + rowe];
+          v = isf ? ((ln == j) ? F_REG : 0.0) : (ise ? jv : 0.0);
+        }
+        ac[j] = v;
+        if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < ND; ++j) {
+        const double dj = bcast(ac[j], j);
+        ok0 = ok0 && (dj > 0.0);
+        dlc = (ln == j) ? dj : dlc;
+        const double lij = (ln > j) ? ac[j] / dj : 0.0;
+#pragma unroll
+        for (int k = j + 1; k < NK; ++k) {
+          ac[k] -= lij * bcast(ac[j], k);                    // column j, still unscaled
+          if ((k - j) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        ac[j] = (ln > j) ? lij : ac[j];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ln < NK) {                                         // the constant columns of the packed factor
+        const int tl = tri(ln);
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+          if (j < ln) L[oL + tl + j] = ac[j];
+      }
+      lds_fence();
+    }
     int st = 1, it = 0;
     for (it = 0; it <= max_iter; ++it) {
       // (the ln id is made opaque in every iteration, and again between its phases: otherwise the ~300 ln-against-
@@ -167,83 +214,82 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__re
         for (int r = 0; r < 8; ++r) aw += wrench_entry(r, comp, dfoot, muf) * L[oW + 8 * foot + r];
         rhs = -grad - aw;
       } else if (ln < NK) rhs = -rp;
-      // ---- the KKT matrix of this step, row `ln` of the lower triangle in registers (words right of the diagonal are
-      // never used): Hq / 1e-6 I + A' diag(sigma) A in the wrench block of the row's foot / [M_b, -Jc_b'].  Every word
-      // any row type needs is read unconditionally at a clamped address, then the row type selects.
+      // ---- the trailing block of this step, row `ln`, columns ND .. NK-1 in registers (words right of the diagonal are
+      // never used): the constant Schur complement + A' diag(sigma) A in the wrench block of the row's foot
       asm volatile("" : "+v"(ln));
-      // this ln's place in the KKT matrix: a qdd row, a contact-wrench row or a floating-base row
-      const bool isq = ln < ND, isf = ln >= ND && ln < NX, ise = ln >= NX && ln < NK;
-      const int rowq = isq ? ln : ND - 1, rowe = ise ? ln - NX : 0;
+      if (!ok0) { st = 2; break; }
+      constexpr int NT = NK - ND;                          // 18
+      const bool isf = ln >= ND && ln < NX;
       const int cf = isf ? ln - ND : 0, foot_l = cf / 6, comp_l = cf % 6;
       double wl[8];                                        // this row's column of the wrench rows
 #pragma unroll
       for (int r = 0; r < 8; ++r) wl[r] = wrench_entry(r, comp_l, dfoot, muf);
-      double a[NK];
+      double w[NT];
 #pragma unroll
-      for (int j = 0; j < NK; ++j) {
-        double v = 0.0;
-        if (j < ND) {
-          const double hv = L[oH + rowq * HS + j], mv = L[oMB + rowe * HS + j];
-          v = isq ? hv : (ise ? mv : 0.0);
-        } else if (j < NX) {
+      for (int t = 0; t < NT; ++t) {
+        const int j = ND + t;
+        double v = ac[j];
+        if (j < NX) {
           const int cj = (j - ND) % 6, fj = (j - ND) / 6;
-          const double v0 = (ln == j) ? F_REG : 0.0;
-          double acc = v0;
+          double acc = 0.0;
 #pragma unroll
           for (int r = 0; r < 8; ++r) acc += L[oSIG + 8 * fj + r] * wl[r] * wrench_entry(r, cj, dfoot, muf);
-          const double jv = -L[oJB + (j - ND) * 7 + rowe];
-          v = isf ? ((foot_l == fj && cj <= comp_l) ? acc : v0) : (ise ? jv : 0.0);
+          v += (isf && foot_l == fj && cj <= comp_l) ? acc : 0.0;
         }
-        a[j] = v;
-        if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);   // (keeps the batch of LDS reads in flight to eight columns)
+        w[t] = v;
       }
       __builtin_amdgcn_sched_barrier(0);
-      // ---- L D L' in registers (no pivoting: quasi-definite).  Step j: l_ij = a_ij / d_j, a_ik -= l_ij a_kj (j < k <= i);
-      // a_kj is ln k's word j.  Lanes <= j run along with l_ij = 0, words right of a ln's diagonal take garbage.
+      // ---- L D L' of the trailing block in registers (no pivoting: quasi-definite).  Step j: l_ij = a_ij / d_j,
+      // a_ik -= l_ij a_kj (j < k <= i); a_kj is lane k's word j.  Lanes <= j run along with l_ij = 0, words right of a
+      // lane's diagonal take garbage.
       bool ok = true;
-      double dl = 1.0;                                     // this ln's pivot
+      double dl = dlc;                                     // this lane's pivot
 #pragma unroll
-      for (int j = 0; j < NK; ++j) {
-        const double dj = bcast(a[j], j);
+      for (int t = 0; t < NT; ++t) {
+        const int j = ND + t;
+        const double dj = bcast(w[t], j);
         ok = ok && ((j < NX) ? (dj > 0.0) : (dj < 0.0));
         dl = (ln == j) ? dj : dl;
-        const double lij = (ln > j) ? a[j] / dj : 0.0;
+        const double lij = (ln > j) ? w[t] / dj : 0.0;
 #pragma unroll
-        for (int k = j + 1; k < NK; ++k) {
-          a[k] -= lij * bcast(a[j], k);                      // column j, still unscaled
-          if ((k - j) % 8 == 0) __builtin_amdgcn_sched_barrier(0);   // (the broadcast words are scalars: no more than eight pairs in flight)
-        }
-        a[j] = (ln > j) ? lij : a[j];
+        for (int u = t + 1; u < NT; ++u) w[u] -= lij * bcast(w[t], ND + u);   // column j, still unscaled
+        w[t] = (ln > j) ? lij : w[t];
         __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
       if (!ok) { st = 2; break; }
-      // ---- forward substitution L y = rhs out of the registers, D, then the factor's strictly lower part to LDS (packed
-      // rows) for the backward substitution L' x = y, which reads it by columns
+      // ---- forward substitution L y = rhs out of the registers, D, then the step's columns of the factor to LDS (packed
+      // rows; the qdd columns stand there since before the loop) for the backward substitution L' x = y, which reads
+      // the factor by columns
       asm volatile("" : "+v"(ln));
       double y = rhs;
 #pragma unroll
       for (int j = 0; j < NK; ++j) {
         const double yj = bcast(y, j);
-        if (ln > j) y -= a[j] * yj;
+        const double lj = (j < ND) ? ac[j] : w[(j < ND) ? 0 : j - ND];
+        if (ln > j) y -= lj * yj;
       }
       y /= dl;
       if (ln < NK) {
         const int tl = tri(ln);
 #pragma unroll
-        for (int j = 0; j < NK - 1; ++j)
-          if (j < ln) L[oL + tl + j] = a[j];
+        for (int j = ND; j < NK - 1; ++j)
+          if (j < ln) L[oL + tl + j] = w[j - ND];
       }
       lds_fence();
-      {
-        double col[NK];                                    // column `ln` of L below the diagonal, one batch of reads
 #pragma unroll
-        for (int j = 1; j < NK; ++j) col[j] = L[oL + tri(j) + ((ln < j) ? ln : 0)];
+      for (int j0 = NK - 12; j0 >= 0; j0 -= 12) {            // column `ln` of L below the diagonal, twelve reads at a time
+        double col[12];
 #pragma unroll
-        for (int j = NK - 1; j >= 1; --j) {
-          const double xj = bcast(y, j);
-          if (ln < j) y -= col[j] * xj;
+        for (int q = 0; q < 12; ++q) { const int j = j0 + q; col[q] = (j >= 1) ? L[oL + tri(j) + ((ln < j) ? ln : 0)] : 0.0; }
+#pragma unroll
+        for (int q = 11; q >= 0; --q) {
+          const int j = j0 + q;
+          if (j >= 1) {
+            const double xj = bcast(y, j);
+            if (ln < j) y -= col[q] * xj;
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       // y: lanes 0..41 dx, lanes 42..47 the new equality multipliers
       if (ln < NK) L[oRHS + ln] = y;
