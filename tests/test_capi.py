@@ -139,6 +139,28 @@ def test_four_vertex_kernel_has_no_spill_code_in_its_stage_loops(tmp_path):
     assert worst <= 3, f"{n} scratch instructions, deepest at loop depth {worst}: spill code inside a stage loop"
 
 
+def test_wave_reductions_take_no_lds_round_trip_and_the_qp_kernel_keeps_seven_instances_per_cu(tmp_path):
+    """Cross-compiled ISA, no GPU needed.  (1) The solver kernels reduce over the wave through v_permlane32/16_swap and
+    DPP (csrc/cmpc_wave.hpp): no ds_bpermute left.  (2) wbc_qp_kernel factorises in registers: its LDS image (problem
+    data + packed factor) lets seven instances share a CU, it is built for two waves per SIMD, and what it spills stays
+    small (the pivot loops are register-only; round 3 kept the matrix in LDS: 48.9 KB, three per CU)."""
+    import re
+    import subprocess
+    for name in ("cmpc_hip.hip", "wbc_qp.hip"):
+        out = tmp_path / (name + ".s")
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               "-o", str(out), os.path.join(_b.PKG, "csrc", name)])
+        isa = out.read_text()
+        assert "ds_bpermute" not in isa, name
+        assert "v_permlane32_swap" in isa and "v_permlane16_swap" in isa and "row_ror:8" in isa, name
+    meta = [b for b in isa[isa.index("amdhsa.kernels"):].split("  - .agpr_count") if "wbc_qp_kernel" in b][0]
+    lds = int(re.search(r"\.group_segment_fixed_size:\s*(\d+)", meta).group(1))
+    vgpr = int(re.search(r"\.vgpr_count:\s*(\d+)", meta).group(1))
+    scratch = int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", meta).group(1))
+    assert 7 * ((lds + 64 + 1279) // 1280 * 1280) <= 160 * 1024, lds
+    assert vgpr <= 256 and scratch <= 256, (vgpr, scratch)
+
+
 def test_queue_order_coefficients_live_in_one_header():
     """csrc/cmpc_order_fit.h is the single home of the predictor's coefficients: the kernel includes it, the host mirror
     parses it, and nothing else spells the numbers out."""
