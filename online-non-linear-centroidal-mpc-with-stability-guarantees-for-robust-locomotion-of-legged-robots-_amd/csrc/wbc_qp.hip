@@ -61,6 +61,14 @@ __device__ __forceinline__ double wave_max(double v) { WBC_BFLY(fmax(a, b)) retu
 __device__ __forceinline__ double wave_min(double v) { WBC_BFLY(fmin(a, b)) return v; }
 __device__ __forceinline__ double wave_sum(double v) { WBC_BFLY(a + b) return v; }
 #undef WBC_BFLY
+// 1 / d by two Newton steps on the hardware estimate (full double accuracy up to the last bit or two; the IEEE division is
+// a ~35-instruction sequence and there is one per pivot on the critical path).  d is a pivot that passed the sign test.
+__device__ __forceinline__ double pivot_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  return r;
+}
 __device__ __forceinline__ double bcast(double v, int src) {
   union { double d; int i[2]; } u; u.d = v;
   u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
@@ -130,7 +138,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__re
         const double dj = bcast(ac[j], j);
         ok0 = ok0 && (dj > 0.0);
         dlc = (ln == j) ? dj : dlc;
-        const double lij = (ln > j) ? ac[j] / dj : 0.0;
+        const double lij = (ln > j) ? ac[j] * pivot_rcp(dj) : 0.0;
 #pragma unroll
         for (int k = j + 1; k < NK; ++k) {
           ac[k] -= lij * bcast(ac[j], k);                    // column j, still unscaled
@@ -250,7 +258,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__re
         const double dj = bcast(w[t], j);
         ok = ok && ((j < NX) ? (dj > 0.0) : (dj < 0.0));
         dl = (ln == j) ? dj : dl;
-        const double lij = (ln > j) ? w[t] / dj : 0.0;
+        const double lij = (ln > j) ? w[t] * pivot_rcp(dj) : 0.0;
 #pragma unroll
         for (int u = t + 1; u < NT; ++u) w[u] -= lij * bcast(w[t], ND + u);   // column j, still unscaled
         w[t] = (ln > j) ? lij : w[t];
@@ -268,7 +276,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__re
         const double lj = (j < ND) ? ac[j] : w[(j < ND) ? 0 : j - ND];
         if (ln > j) y -= lj * yj;
       }
-      y /= dl;
+      y *= pivot_rcp(dl);
       if (ln < NK) {
         const int tl = tri(ln);
 #pragma unroll
