@@ -43,3 +43,35 @@ moved = (ro.plan_pos.cpu().numpy() != sc.plan_pos[None]).any(axis=2).sum(axis=1)
 print(f"(b) {B} parallel walks, t = {start} ... {start + ticks}: {alive} of {B} alive after {ticks} ticks, mean iterations {np.mean(its):.1f}, "
       f"{1e3 * dt / ticks:.1f} ms per tick = {B * ticks / dt:.0f} closed-loop solves/s (builder + solve + write-back + advance), "
       f"plan entries rewritten per walk: min {moved.min()} max {moved.max()}")
+
+# (c) the same B closed loops with the whole-body QP inside every tick (code/simulation.py:193-232 per robot: the MPC, then
+# get_joint_torques on the MPC's desired CoM).  The rigid-body model is the synthetic stand-in of the GPU test (fixed task
+# Jacobians per robot, the CoM task's feed-forward acceleration = the MPC's CoM_acc): what is timed is the whole tick on
+# the device -- records, MPC solve, plan write-back, QP assembly of the stand-in, QP solve.
+from cmpc_amd import wbc
+ro = BatchedRollout(sc, spec, B, device="cuda:0", hw_measured=hw, hw_offset=rng.normal(0, 0.05, size=(B, 3)))
+Hq0, Fq0, Mm, hh, Jc = (torch.from_numpy(np.ascontiguousarray(np.tile(a, (B // 256,) + (1,) * (a.ndim - 1)))).cuda() for a in wl.wbc_synthetic(256, seed=77))
+Jcom = torch.from_numpy(np.tile(rng.normal(0, 0.4, size=(256, 3, 30)), (B // 256, 1, 1))).cuda()
+Jcom[:, :, 3:6] += torch.eye(3, dtype=torch.float64, device="cuda:0")
+Hq = (Hq0 + 50.0 * Jcom.transpose(1, 2) @ Jcom).contiguous()
+
+
+def model(rollout, desired):
+    g = torch.cat([desired["gamma_l"][:, None].expand(-1, 6), desired["gamma_r"][:, None].expand(-1, 6)], dim=1)
+    Fq = (Fq0 - 50.0 * torch.einsum("brn,br->bn", Jcom, desired["com_acc"])).contiguous()
+    return Hq, Fq, Mm, hh, (Jc * g[:, :, None]).contiguous()
+
+
+ro.attach_whole_body(wbc.BatchedInverseDynamicsQP(foot_size=0.1, mu=0.5, device="cuda:0"), model)
+ro.reset(start, com, dcom)
+for i in range(3):
+    ro.step()
+ro.reset(start, com, dcom)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+okq = 0
+for i in range(ticks):
+    ro.step(); okq += int((ro.last_wbc[3] == 0).sum())
+torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+print(f"(c) the same {B} walks with the whole-body QP inside every tick: {1e3 * dt2 / ticks:.1f} ms per tick = {B * ticks / dt2:.0f} whole "
+      f"ticks/s (MPC + QP; {1e3 * (dt2 - dt) / ticks:.1f} ms of it for the stand-in model's assembly and the QP), QPs converged "
+      f"{okq / (B * ticks):.4f}, {int(ro.alive.sum())} of {B} alive")
