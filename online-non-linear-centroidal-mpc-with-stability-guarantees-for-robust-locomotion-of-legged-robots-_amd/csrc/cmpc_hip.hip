@@ -133,14 +133,14 @@ __global__ void __launch_bounds__(64 * NW, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) 
   }
 }
 
-// The pipelined pair (cmpc::Solver<4, 1, true>): two waves per instance, two LDS images + 16 exchange words.  For batches
-// that do not fill the GPU (cmpc_solve_batch picks it when B <= the pair kernel's resident grid): same results bit for
-// bit, an instance finishes ~1.4x sooner.
-template <int NV>
-__global__ void __launch_bounds__(128, 1) cmpc_solve_pair_kernel(cmpc::KArgs ka, int *ticket,
+// The pipelined pair (cmpc::Solver<4, 1, true>): two waves per instance, two LDS images.  For batches that do not keep
+// the GPU full for long (cmpc_solve_batch picks it up to 20 instances per CU): same results bit for bit, an instance
+// finishes ~1.55x sooner.  WPS = waves per SIMD the build is for: 2 (256 registers, three pairs per CU) or 1.
+template <int NV, int WPS>
+__global__ void __launch_bounds__(128, WPS) cmpc_solve_pair_kernel(cmpc::KArgs ka, int *ticket,
                                                                                   const int *__restrict__ order) {
   using D = cmpc::Dims<NV, 1>;
-  __shared__ __attribute__((aligned(16))) double lds[2 * D::LDS_DOUBLES + cmpc::Solver<NV, 1, true>::XCH_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double lds[2 * D::LDS_DOUBLES];
   __shared__ int next;
   double *slab = ka.scratch + (size_t)blockIdx.x * ka.scratch_stride;
   const size_t nrec = CMPC_NREC(ka.sp.N), nsol = CMPC_NSOL(ka.sp.N, NV), nstate = CMPC_NSTATE(ka.sp.N, NV);
@@ -232,6 +232,7 @@ struct cmpc_handle {
   int grid = 0;
   int pair_grid = 0;                                // resident grid of the pipelined pair kernel (nv = 4)
   int pair_max_batch = 0;                           // largest batch that goes to the pair kernel, 0 = never used
+  int pair_per_cu = 2;
   int num_cu = 0;
   size_t slab_doubles = 0;
   double *scratch = nullptr;
@@ -329,16 +330,22 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   h->num_cu = prop.multiProcessorCount;
   h->grid = h->num_cu * resident_per_cu(spec->nv);
   if (spec->nv == 4) {
-    // pairs a CU holds: LDS (two images) in 1280-byte granules; the pair kernel is built for one wave per SIMD (up to 512
-    // registers), i.e. at most two pairs per CU
-    const size_t granule = 1280, alloc = (sizeof(double) * (2 * cmpc::Dims<4>::LDS_DOUBLES + cmpc::Solver<4, 1, true>::XCH_DOUBLES) + 16 + granule - 1) / granule * granule;
+    // pairs a CU holds: LDS (exactly two images: the exchange words stand in the second image's unused P region) in
+    // 1280-byte granules -> three, six waves per CU; the pair kernel is built for two waves per SIMD (256 registers, no
+    // scratch).  (CMPC_PAIR_PER_CU=2: round 4's first form -- two pairs per CU, the build for one wave per SIMD.)
+    const size_t granule = 1280, alloc = (sizeof(double) * (2 * cmpc::Dims<4>::LDS_DOUBLES) + 16 + granule - 1) / granule * granule;
     int n = (int)((160 * 1024) / alloc);
-    if (n > 2) n = 2;
-    h->pair_grid = h->num_cu * (n < 1 ? 1 : n);
-    // Up to four rounds of pairs the pair kernel is the faster one (an instance-iteration takes 0.4 ms in a pair against
-    // 0.65 - 1.2 ms in one of two to six waves of a CU, and a short queue is mostly its longest instance): measured
-    // crossover between 2048 and 2560 instances on 256 CUs (profiles/r04h_pair_crossover.txt)
-    h->pair_max_batch = 4 * h->pair_grid;
+    if (n > 3) n = 3;
+    if (const char *e = getenv("CMPC_PAIR_PER_CU")) {
+      if (atoi(e) == 2 && n > 2) n = 2;
+    }
+    h->pair_per_cu = n < 1 ? 1 : n;
+    h->pair_grid = h->num_cu * h->pair_per_cu;
+    // The pair kernel is the faster one while the queue is short (an instance-iteration takes 0.4 - 0.5 ms in a pair
+    // against 0.65 - 1.2 ms in one of two to six single waves of a CU, and a short queue is mostly its longest instance).
+    // Measured crossover on 256 CUs: between 6144 and 7168 instances (config 4), 4096 and 6144 (config 3) with three pairs
+    // per CU; between 2048 and 2560 with two (profiles/r04h_pair_crossover.txt, r04m_pair3_crossover.txt)
+    h->pair_max_batch = (h->pair_per_cu >= 3 ? 20 : 8) * h->num_cu;
     if (const char *e = getenv("CMPC_PAIR")) {         // developer knob: 0 = never, 1 = always (A/B measurements)
       h->pair_max_batch = (atoi(e) == 0) ? 0 : 1 << 30;
     }
@@ -416,7 +423,11 @@ int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, cons
                      mu_word, h->order + B, h->ticket);
   hipLaunchKernelGGL(cmpc_order_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->order + B, h->order, h->ticket);
   if (h->spec.nv == 4 && B <= h->pair_max_batch)     // the batch does not fill the GPU for long: two waves per instance
-    hipLaunchKernelGGL((cmpc_solve_pair_kernel<4>), dim3(B < h->pair_grid ? B : h->pair_grid), dim3(128), 0, st, ka, h->ticket, h->order);
+  {
+    const dim3 pg(B < h->pair_grid ? B : h->pair_grid);
+    if (h->pair_per_cu >= 3) hipLaunchKernelGGL((cmpc_solve_pair_kernel<4, 2>), pg, dim3(128), 0, st, ka, h->ticket, h->order);
+    else hipLaunchKernelGGL((cmpc_solve_pair_kernel<4, 1>), pg, dim3(128), 0, st, ka, h->ticket, h->order);
+  }
   else if (h->spec.nv == 4)
     hipLaunchKernelGGL((cmpc_solve_kernel<4, 1>), dim3(grid), dim3(64), 0, st, ka, h->ticket, h->order);
   else

@@ -303,6 +303,10 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   // PIPE: words behind the two LDS images.  [0..5] error measures, [6] ap, [7] ad, [8..9] factorisation verdict of the
   // sweep step in hand (by step parity), [16 ..): du_k of the forward sweep by stage parity (read by the slack wave)
   static constexpr int XCH_DU = 16, XCH_DOUBLES = XCH_DU + 2 * D::NU;
+  // They stand in the P region of image 1, which nothing else uses (the cost-to-go lives in image 0 only): the pair's
+  // allocation is exactly two images, 42 granules of 1280 bytes -> three pairs per CU.
+  static_assert(!PIPE || XCH_DOUBLES <= D::P_DOUBLES, "the exchange words fit in the unused P region of the second image");
+  static constexpr int XCH_AT = D::LDS_DOUBLES + D::oP;
   static_assert(!PIPE || NW == 1, "the pipelined pair runs the one-wave solver");
   static constexpr int NF = D::NF, NU = D::NU, NXA = D::NXA, NZ = D::NZ, NI = D::NI, NH = D::NH, WS = D::WS;
   static_assert(NW == 1 || NU <= 64, "the input rows (pivot chains, substitutions) live in the first wave");
@@ -1619,7 +1623,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       // before, then evaluates stage N - j into that image.  One workgroup barrier per step.  A failed factorisation is
       // published in the exchange words behind the two images and seen by both waves after the barrier of its step.
       // (the verdict of step j sits in word 8 + (j & 1): wave 0 may be a step ahead of wave 1's read of the last one)
-      double *xch = ldsR + 2 * D::LDS_DOUBLES;
+      double *xch = ldsR + XCH_AT;
       if (lane == 0 && wv == 0) { xch[8] = 0.0; xch[9] = 0.0; }
       CMPC_SYNC_WG();
       for (int j = 0; j <= N + 2; ++j) {
@@ -1692,7 +1696,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     constexpr int NIH = (NI + WS - 1) / WS;
     const double tau = fmax(0.99, 1 - mu);
     double lap = 1.0, lad = 1.0;
-    double *xdu = ldsR + 2 * D::LDS_DOUBLES + XCH_DU;
+    double *xdu = ldsR + XCH_AT + XCH_DU;
     constexpr bool MERGE = D::W_MERGE;
     const bool isA = lane < NU;
     const int lb = MERGE ? lane - NU : lane;
@@ -1874,7 +1878,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     }
     if constexpr (PIPE) {
       CMPC_SYNC_WG();                          // the slack wave has reduced the step bounds
-      const double *xch = ldsR + 2 * D::LDS_DOUBLES;
+      const double *xch = ldsR + XCH_AT;
       ap = xch[6]; ad = xch[7];
     } else {
       ap = red_min(lap); ad = red_min(lad);
@@ -1889,7 +1893,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     constexpr int NIH = (NI + WS - 1) / WS;
     const double tau = fmax(0.99, 1 - mu);
     double lap = 1.0, lad = 1.0;
-    double *xch = ldsR + 2 * D::LDS_DOUBLES;
+    double *xch = ldsR + XCH_AT;
     gsync();                                  // this wave's stores of the evaluation and of the last step
     int cur = D::oXK, nxt = D::oXN1;          // the chain wave's dx_k / dx_{k+1} ping-pong
     for (int k = 0; k <= N; ++k) {
@@ -2163,7 +2167,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       if constexpr (PIPE) {
         // the error measures were gathered by the evaluating wave: handed to both through the exchange words; the same
         // barrier orders the slab writes of the sweep (both waves') before the vector sweep of wave 0
-        double *xch = ldsR + 2 * D::LDS_DOUBLES;
+        double *xch = ldsR + XCH_AT;
         if (wv == 1 && lane == 0) { xch[0] = e_d; xch[1] = e_p; xch[2] = e_c; xch[3] = e_cmu; xch[4] = sm; xch[5] = nm; }
         pair_sync();
         e_d = xch[0]; e_p = xch[1]; e_c = xch[2]; e_cmu = xch[3]; sm = xch[4]; nm = xch[5];
