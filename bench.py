@@ -366,6 +366,12 @@ def main():
                  note="final scaled KKT error of the usable instances (status 0 or 3)")
 
     nw = 2 if spec.nv == 8 else 1
+    # which kernel cmpc_solve_batch launches for this batch (csrc/cmpc_hip.hip: the pipelined pair up to 20 instances per CU)
+    cus, Bl = torch.cuda.get_device_properties(device).multi_processor_count, hi - lo
+    forced = os.environ.get("CMPC_PAIR")
+    pair = spec.nv == 4 and (forced != "0") and (forced == "1" or Bl <= 20 * cus) and os.environ.get("CMPC_PAIR_PER_CU") != "2"
+    pair2 = spec.nv == 4 and (forced != "0") and (forced == "1" or Bl <= 8 * cus) and os.environ.get("CMPC_PAIR_PER_CU") == "2"
+    kernel_name = "cmpc_solve_pair_kernel<4, 2>" if pair else "cmpc_solve_pair_kernel<4, 1>" if pair2 else f"cmpc_solve_kernel<{spec.nv}, {nw}>"
     traffic = measured_traffic(args.workload, args.batch, spec.N)
     result = {
         "metric": f"centroidal-MPC solves/sec, N={spec.N} horizon",
@@ -391,7 +397,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                      "traffic_source": traffic[1] if traffic else None,
-                     "kernel": f"cmpc_solve_kernel<{spec.nv}, {nw}>", "kernel_ms": kernel_ms,
+                     "kernel": kernel_name, "kernel_ms": kernel_ms,
                      "kernel_ms_min": float(np.min(k_ms)), "kernel_ms_max": float(np.max(k_ms)), "kernel_launches_timed": len(k_ms),
                      "kernel_ms_note": "average over the timed launches, HIP events on the launch stream around each solve "
                                        "call (memset, two queue-order kernels, the solve kernel)",
