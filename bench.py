@@ -215,6 +215,8 @@ def main():
                     help="seed of the synthetic batch (default: the configuration's own, SURVEY 8d)")
     ap.add_argument("--launch-timeout", type=float, default=3000.0,
                     help="bare --gpus N launcher: seconds after which ranks still running are stopped (exit code 124)")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "single", "pair"],
+                    help="cmpc_spec.kernel of the solver handles (auto = the library's choice by batch size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the pipelined / warm-start / batch-sweep legs")
     args = ap.parse_args()
@@ -280,8 +282,13 @@ def main():
     spec, rec_all = wl.make_workload(args.workload, B=B_total, seed=args.seed)
     if spec.N > 20:
         spec.max_iter = 150                                        # long horizons take more iterations
-    lo, hi = cdist.shard_bounds(B_total, world, rank)
-    rec = torch.from_numpy(rec_all[lo:hi].copy()).to(device)       # resident in HBM before timing
+    spec.kernel = {"auto": 0, "single": 1, "pair": 2}[args.kernel]
+    # the batch is dealt to the ranks by predicted cost (cmpc_amd.dist.shard_order): a step ends with its slowest
+    # rank, and a contiguous shard's makespan moves with the stragglers it happens to hold
+    order = cdist.shard_order(rec_all, spec, world)
+    rows = cdist.dealt_rows(order, world, rank)
+    lo, hi = 0, int(rows.shape[0])                                 # (this rank's share: hi - lo instances)
+    rec = torch.from_numpy(rec_all[rows].copy()).to(device)        # resident in HBM before timing
     n_handles = max(2, args.streams)
     solvers = [BatchedCentroidalMPC(spec, device=device) for _ in range(n_handles)]
     streams = [torch.cuda.Stream(device=device) for _ in range(n_handles)]
@@ -303,7 +310,7 @@ def main():
             packed = torch.cat((fb, kkt[:, None], status.to(fb.dtype)[:, None], iters.to(fb.dtype)[:, None]), dim=1)
             if ev:
                 ev[2].record()
-            full = cdist.gather_shards(packed, B_total) if records is rec else packed   # the ONE collective
+            full = cdist.gather_dealt(packed, order) if records is rec else packed      # the ONE collective (rows back in input order)
             if ev:
                 ev[3].record()
                 marks.append(ev)
@@ -365,13 +372,7 @@ def main():
     kkt_q = dict(quantiles(kk[use], [0.5, 0.9, 0.99]), max=float(kk[use].max().item()) if bool(use.any()) else None,
                  note="final scaled KKT error of the usable instances (status 0 or 3)")
 
-    nw = 2 if spec.nv == 8 else 1
-    # which kernel cmpc_solve_batch launches for this batch (csrc/cmpc_hip.hip: the pipelined pair up to 20 instances per CU)
-    cus, Bl = torch.cuda.get_device_properties(device).multi_processor_count, hi - lo
-    forced = os.environ.get("CMPC_PAIR")
-    pair = spec.nv == 4 and (forced != "0") and (forced == "1" or Bl <= 20 * cus) and os.environ.get("CMPC_PAIR_PER_CU") != "2"
-    pair2 = spec.nv == 4 and (forced != "0") and (forced == "1" or Bl <= 8 * cus) and os.environ.get("CMPC_PAIR_PER_CU") == "2"
-    kernel_name = "cmpc_solve_pair_kernel<4, 2>" if pair else "cmpc_solve_pair_kernel<4, 1>" if pair2 else f"cmpc_solve_kernel<{spec.nv}, {nw}>"
+    kernel_name = solvers[0].last_kernel_name()                   # what the library launched (cmpc_last_kernel_name)
     traffic = measured_traffic(args.workload, args.batch, spec.N)
     result = {
         "metric": f"centroidal-MPC solves/sec, N={spec.N} horizon",
@@ -385,7 +386,7 @@ def main():
                    "global_batch": B_total, "horizon": spec.N, "tol": spec.tol, "acc_tol": spec.acc_tol,
                    "max_iter": spec.max_iter, "mean_iterations": mean_iters, "seed": args.seed if args.seed is not None else wl.CONFIGS[args.workload][0],
                    "counted_as_solves": "status 0 only (scaled KKT error <= tol)",
-                   "parallelism": f"batch-sharded x{world}, final all-gather of (x1,u0,kkt,status,iters); "
+                   "parallelism": f"batch dealt over {world} rank(s) by predicted cost, final all-gather of (x1,u0,kkt,status,iters); "
                                   f"{'strictly serial launches' if S == 1 else f'steps alternate over {S} HIP streams'}"},
         "iterations": it_q, "kkt": kkt_q,
         "outcome": dict(frac, usable_solves_per_s=rate_all * (frac["converged"] + frac["acceptable"]),
@@ -452,6 +453,26 @@ def main():
                               "converged_solves_per_s": Bs * reps / els * cs_}
             del d
         result["batch_sweep"] = sweep
+        # --- the headline over several seeds: the configuration's own and two that neither the queue-order fit (seed
+        # 424242) nor any tuning has seen.  `value` moves with one or two late stragglers of a batch.
+        own = args.seed if args.seed is not None else wl.CONFIGS[args.workload][0]
+        seeds = {}
+        for sd in (own, 777, 31337):
+            if sd == own:
+                seeds[str(sd)] = {"value": value, "all_instances_per_s": rate_all, "converged": frac["converged"]}
+                continue
+            _, rs = wl.make_workload(args.workload, B=args.batch, N=spec.N, seed=sd)
+            d = torch.from_numpy(rs).to(device)
+            reps = max(3, args.steps // 2)
+            els, fs, _ = timed(1, reps, 1, records=d)
+            cs_ = float((fs[:, -2] == 0).double().mean().item())
+            seeds[str(sd)] = {"value": args.batch * reps / els * cs_, "all_instances_per_s": args.batch * reps / els, "converged": cs_}
+            del d
+        vals, alls = [v["value"] for v in seeds.values()], [v["all_instances_per_s"] for v in seeds.values()]
+        result["seeds"] = {"per_seed": seeds, "value_min": float(np.min(vals)), "value_median": float(np.median(vals)),
+                           "all_instances_per_s_min": float(np.min(alls)), "all_instances_per_s_median": float(np.median(alls)),
+                           "note": "same serial measurement as `value` on fresh batches of the same distribution; the first "
+                                   "seed is the configuration's own (= `value`)"}
 
     if world == 1 and not args.no_extras:
         # --- the next row of the scope table: batched whole-body inverse-dynamics QP, B = 65536
@@ -477,7 +498,7 @@ def main():
                             "hbm_frac": bytes_q * Bq / (ms_q * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "note": "code/inverse_dynamics.py:92-134 for 65536 robots (1024 distinct synthetic instances, "
                                     "30 dofs, double support), wbc_qp_kernel, KKT error <= 1e-9; one wave per QP, L D L' of the "
-                                    "48 x 48 KKT matrix in registers (48 serial pivots per Newton step), seven QPs per CU"}
+                                    "48 x 48 KKT matrix in registers (its 30 barrier-free pivots once per instance, 18 pivots per Newton step), seven QPs per CU"}
         if not args.no_cpu_baseline:
             from oracle import wbc_qp_oracle as wq        # the numpy oracle of the QP, timed on one core
             t0 = time.perf_counter()

@@ -40,6 +40,20 @@ def build_hip_profile(force=False):
     return out
 
 
+def build_hip_dev(force=False):
+    """Developer variant (tools/ only; never loaded by the package unless CMPC_LIB_PATH names it): -DCMPC_DEV_KNOBS compiles
+    in the environment knobs of the occupancy / kernel-choice studies (CMPC_WG_PER_CU, CMPC_PAIR, CMPC_PAIR_PER_CU), which
+    the shipped library does not read."""
+    src = os.path.join(PKG, "csrc", "cmpc_hip.hip")
+    deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"), os.path.join(PKG, "csrc", "cmpc_wave.hpp"),
+            os.path.join(ROOT, "include", "cmpc.h")]
+    out = os.path.join(ROOT, "tools", "libcmpc_amd_dev.so")
+    if force or _newer(out, deps):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               "-DCMPC_DEV_KNOBS", "-o", out, src, os.path.join(PKG, "csrc", "wbc_qp.hip")])
+    return out
+
+
 def build_oracle(force=False):
     out = os.path.join(ROOT, "oracle", "libcmpc_oracle.so")
     deps = [os.path.join(ROOT, "oracle", "cmpc_oracle.c"), os.path.join(ROOT, "include", "cmpc.h")]
@@ -55,7 +69,8 @@ def build_emu(force=False):
     deps = [src, os.path.join(PKG, "csrc", "cmpc_kernel.hpp"), os.path.join(PKG, "csrc", "cmpc_lds_asm.hpp"), os.path.join(PKG, "csrc", "cmpc_wave.hpp"),
             os.path.join(ROOT, "include", "cmpc.h")]
     if force or _newer(out, deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", out, src])
+        # (-mfma -ffp-contract=off: the kernel's explicit CMPC_FMA are single instructions, and nothing else is fused)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", out, src])
     return out
 
 

@@ -56,7 +56,15 @@ typedef struct cmpc_spec {
   double acc_tol;             /* acceptable level (CMPC_ACCEPTABLE), > 0, default 1e-4: tighter than what the
                                  reference's IPOPT configuration (tol = 1e-3, :128; constr_viol_tol and
                                  compl_inf_tol 1e-4 by default) returns as full success              */
+  int32_t kernel;             /* CMPC_KERNEL_*: which solver kernel cmpc_solve_batch launches (create-time choice;
+                                 results are bit for bit the same either way)                         */
+  int32_t reserved;           /* 0                                                                    */
 } cmpc_spec;
+
+/* Solver kernel of a handle (cmpc_spec.kernel).  AUTO: the pipelined pair (two wavefronts per instance) for batches that
+ * do not fill the GPU for long, one wavefront per instance otherwise.  SINGLE / PAIR force one of them for every batch
+ * size (nv = 4 only has both; nv = 8 always runs its two-wave kernel and accepts AUTO or SINGLE). */
+enum { CMPC_KERNEL_AUTO = 0, CMPC_KERNEL_SINGLE = 1, CMPC_KERNEL_PAIR = 2 };
 
 /* Doubles per instance in the parameter / solution records. */
 #define CMPC_NREC(N) (24 + 19 * (N))
@@ -92,8 +100,9 @@ void cmpc_default_spec(cmpc_spec *spec, int32_t N, int32_t nv);
 int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out);
 int cmpc_destroy(cmpc_handle *h);
 
-/* Device scratch of a handle for batches of up to B instances: the slabs (bounded by the resident grid of a 256-CU
- * part, allocated by cmpc_create) plus the queue-order arrays (8 bytes per instance; (re)allocated by the first
+/* Device scratch of a handle for batches of up to B instances: the slabs (bounded by the resident grid of the current
+ * HIP device -- its CU count times the workgroups a CU holds; 256 CUs are assumed when no device can be queried --,
+ * allocated by cmpc_create) plus the queue-order arrays (8 bytes per instance; (re)allocated by the first
  * cmpc_solve_batch call with a larger B than any before -- that call synchronises the device and must not be made
  * under stream capture; later calls with B up to that size allocate nothing). */
 size_t cmpc_workspace_bytes(const cmpc_spec *spec, int32_t B);
@@ -132,6 +141,9 @@ int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, cons
 /* Average kernel time (ms) of the last cmpc_solve_batch on this handle, measured with
  * HIP events on the launch stream; synchronises that stream. */
 int cmpc_last_kernel_ms(cmpc_handle *h, float *ms);
+/* Name of the solver kernel the last cmpc_solve_batch on this handle launched (e.g. "cmpc_solve_kernel<4, 1>",
+ * "cmpc_solve_pair_kernel<4, 2>"), as a profiler lists it; "" before the first launch.  Owned by the library. */
+const char *cmpc_last_kernel_name(cmpc_handle *h);
 
 /*
  * Batched parameter builder = front half of centroidal_mpc.solve (code/centroidal_mpc_vertices.py:482-600)

@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("CMPC_LIB_PATH") or os.path.join(_HERE, "libcmpc_amd.s
 
 #: every symbol include/cmpc.h declares
 SYMBOLS = ("cmpc_default_spec", "cmpc_create", "cmpc_destroy", "cmpc_workspace_bytes",
-           "cmpc_solve_batch", "cmpc_solve_batch_state", "cmpc_last_kernel_ms", "cmpc_last_error", "cmpc_version",
+           "cmpc_solve_batch", "cmpc_solve_batch_state", "cmpc_last_kernel_ms", "cmpc_last_kernel_name", "cmpc_last_error",
+           "cmpc_version",
            "cmpc_tables_create", "cmpc_tables_destroy", "cmpc_build_records",
            "cmpc_tables_set_plan_slots", "cmpc_build_records_planned")
 #: every symbol include/cmpc_wbc.h declares (batched whole-body QP, same library)
@@ -49,6 +50,8 @@ def load():
     lib.cmpc_solve_batch_state.restype = ctypes.c_int
     lib.cmpc_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.cmpc_last_kernel_ms.restype = ctypes.c_int
+    lib.cmpc_last_kernel_name.argtypes = [vp]
+    lib.cmpc_last_kernel_name.restype = ctypes.c_char_p
     lib.cmpc_last_error.argtypes = [vp]
     lib.cmpc_last_error.restype = ctypes.c_char_p
     lib.cmpc_tables_create.argtypes = [ctypes.c_int, i32] + [vp] * 7 + [ctypes.POINTER(vp)]

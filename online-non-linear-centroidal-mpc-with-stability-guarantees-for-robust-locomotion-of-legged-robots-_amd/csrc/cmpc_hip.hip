@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64 * NW, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) 
 template <int NV, int WPS>
 __global__ void __launch_bounds__(128, WPS) cmpc_solve_pair_kernel(cmpc::KArgs ka, int *ticket,
                                                                                   const int *__restrict__ order) {
-  using D = cmpc::Dims<NV, 1>;
+  using D = cmpc::Dims<NV, 1, true>;
   __shared__ __attribute__((aligned(16))) double lds[2 * D::LDS_DOUBLES];
   __shared__ int next;
   double *slab = ka.scratch + (size_t)blockIdx.x * ka.scratch_stride;
@@ -234,6 +234,8 @@ struct cmpc_handle {
   int pair_max_batch = 0;                           // largest batch that goes to the pair kernel, 0 = never used
   int pair_per_cu = 2;
   int num_cu = 0;
+  int slabs = 0;                                    // slabs allocated: every launch grid stays within it
+  const char *last_kernel = "";                     // name of the solver kernel the last launch used
   size_t slab_doubles = 0;
   double *scratch = nullptr;
   int *ticket = nullptr;                            // ORDER_COUNTERS words: the ticket and the counters of the queue order
@@ -273,7 +275,9 @@ static int fail(cmpc_handle *h, const std::string &msg) {
 static bool spec_ok(const cmpc_spec *s) {
   return s && s->struct_size == (int32_t)sizeof(cmpc_spec) && s->N >= 1 && s->N <= CMPC_MAX_N &&
          (s->nv == 4 || s->nv == 8) && s->max_iter >= 1 && s->delta > 0 && s->tol > 0 && s->tol < INFINITY &&
-         s->acc_tol > 0 && s->acc_tol < INFINITY;
+         s->acc_tol > 0 && s->acc_tol < INFINITY &&
+         (s->kernel == CMPC_KERNEL_AUTO || s->kernel == CMPC_KERNEL_SINGLE || (s->kernel == CMPC_KERNEL_PAIR && s->nv == 4)) &&
+         s->reserved == 0;
 }
 static size_t lds_bytes(int nv) {
   return sizeof(double) * (nv == 4 ? cmpc::Dims<4>::LDS_DOUBLES : cmpc::Dims<8, cmpc::WAVES_NV8>::LDS_DOUBLES) + 16;
@@ -290,6 +294,27 @@ static int resident_per_cu(int nv) {
   if (n * waves > 8) n = 8 / waves;
   return n < 1 ? 1 : n;
 }
+// Pairs of the pipelined kernel a CU holds (nv = 4): two LDS images per pair (the exchange words stand in the second
+// image's unused P region), in 1280-byte granules -> three, six waves per CU; the pair kernel is built for two waves per
+// SIMD (256 registers, no scratch).
+static int pairs_per_cu() {
+  const size_t granule = 1280, alloc = (sizeof(double) * (2 * cmpc::Dims<4, 1, true>::LDS_DOUBLES) + 16 + granule - 1) / granule * granule;
+  int n = (int)((160 * 1024) / alloc);
+  if (n > 3) n = 3;
+  return n < 1 ? 1 : n;
+}
+// Slabs a handle allocates: one per workgroup of the largest grid any of its kernels is launched with.
+static int slab_count(const cmpc_spec *s, int num_cu) {
+  const int g = num_cu * resident_per_cu(s->nv), pg = (s->nv == 4) ? num_cu * pairs_per_cu() : 0;
+  return g > pg ? g : pg;
+}
+static int current_device_cus() {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1)
+    return 256;                                      // no device to ask (host-only callers): an MI355X
+  return prop.multiProcessorCount;
+}
 
 extern "C" {
 
@@ -302,20 +327,20 @@ void cmpc_default_spec(cmpc_spec *s, int32_t N, int32_t nv) {
   s->cz_max = 0.76; s->box[0] = 0.01; s->box[1] = 0.005; s->box[2] = 0.00005;
   s->foot_length = 0.25; s->foot_width = 0.13; s->prox = 1e-4; s->relax = 1e-8; s->tol = 1e-8;
   s->acc_tol = 1e-4;
+  s->kernel = CMPC_KERNEL_AUTO;
 }
 
 size_t cmpc_workspace_bytes(const cmpc_spec *spec, int32_t B) {
   if (!spec_ok(spec)) return 0;
-  // the slab count is bounded by the resident grid, not by B
-  int grid = 256 * resident_per_cu(spec->nv);
-  if (B > 0 && B < grid) grid = B;
+  // the slab count is bounded by the resident grid of the device, not by B (cmpc_create allocates all of them)
+  const int grid = slab_count(spec, current_device_cus());
   return (size_t)grid * slab_doubles(spec) * sizeof(double) + ORDER_COUNTERS * sizeof(int) + 2 * (size_t)(B > 0 ? B : 0) * sizeof(int);
 }
 
 int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   if (!out) return fail(nullptr, "cmpc_create: null out pointer");
   *out = nullptr;
-  if (!spec_ok(spec)) return fail(nullptr, "cmpc_create: invalid spec (struct_size = sizeof(cmpc_spec), N in [1,64], nv in {4,8}, tol > 0, acc_tol > 0)");
+  if (!spec_ok(spec)) return fail(nullptr, "cmpc_create: invalid spec (struct_size = sizeof(cmpc_spec), N in [1,64], nv in {4,8}, tol > 0, acc_tol > 0, kernel a CMPC_KERNEL_* value)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "cmpc_create: no HIP device");
   if (device < 0 || device >= ndev) return fail(nullptr, "cmpc_create: bad device index");
@@ -330,35 +355,37 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
   h->num_cu = prop.multiProcessorCount;
   h->grid = h->num_cu * resident_per_cu(spec->nv);
   if (spec->nv == 4) {
-    // pairs a CU holds: LDS (exactly two images: the exchange words stand in the second image's unused P region) in
-    // 1280-byte granules -> three, six waves per CU; the pair kernel is built for two waves per SIMD (256 registers, no
-    // scratch).  (CMPC_PAIR_PER_CU=2: round 4's first form -- two pairs per CU, the build for one wave per SIMD.)
-    const size_t granule = 1280, alloc = (sizeof(double) * (2 * cmpc::Dims<4>::LDS_DOUBLES) + 16 + granule - 1) / granule * granule;
-    int n = (int)((160 * 1024) / alloc);
-    if (n > 3) n = 3;
-    if (const char *e = getenv("CMPC_PAIR_PER_CU")) {
-      if (atoi(e) == 2 && n > 2) n = 2;
-    }
-    h->pair_per_cu = n < 1 ? 1 : n;
+    h->pair_per_cu = pairs_per_cu();
+#ifdef CMPC_DEV_KNOBS
+    // (round 4's first form of the pair kernel -- two pairs per CU, the build for one wave per SIMD)
+    if (const char *e = getenv("CMPC_PAIR_PER_CU")) { if (atoi(e) == 2 && h->pair_per_cu > 2) h->pair_per_cu = 2; }
+#endif
     h->pair_grid = h->num_cu * h->pair_per_cu;
     // The pair kernel is the faster one while the queue is short (an instance-iteration takes 0.4 - 0.5 ms in a pair
     // against 0.65 - 1.2 ms in one of two to six single waves of a CU, and a short queue is mostly its longest instance).
     // Measured crossover on 256 CUs: between 6144 and 7168 instances (config 4), 4096 and 6144 (config 3) with three pairs
-    // per CU; between 2048 and 2560 with two (profiles/r04h_pair_crossover.txt, r04m_pair3_crossover.txt)
+    // per CU; between 2048 and 2560 with two (profiles/r04h_pair_crossover.txt, r04m_pair3_crossover.txt).  The caller
+    // can fix the choice when the handle is created (cmpc_spec.kernel): the results are the same bit for bit.
     h->pair_max_batch = (h->pair_per_cu >= 3 ? 20 : 8) * h->num_cu;
-    if (const char *e = getenv("CMPC_PAIR")) {         // developer knob: 0 = never, 1 = always (A/B measurements)
-      h->pair_max_batch = (atoi(e) == 0) ? 0 : 1 << 30;
-    }
+    if (spec->kernel == CMPC_KERNEL_SINGLE) h->pair_max_batch = 0;
+    if (spec->kernel == CMPC_KERNEL_PAIR) h->pair_max_batch = 1 << 30;
+#ifdef CMPC_DEV_KNOBS
+    if (const char *e = getenv("CMPC_PAIR")) h->pair_max_batch = (atoi(e) == 0) ? 0 : 1 << 30;
+#endif
   }
-  if (const char *e = getenv("CMPC_WG_PER_CU")) {      // developer knob: fewer resident workgroups per CU (occupancy studies)
+  h->slabs = slab_count(spec, h->num_cu);              // (both kernels' grids: either may be launched on this handle)
+#ifdef CMPC_DEV_KNOBS
+  // Developer build only (tools/, never the shipped library): fewer resident workgroups per CU for occupancy studies
+  if (const char *e = getenv("CMPC_WG_PER_CU")) {
     const int n = atoi(e);
     if (n >= 1 && n < resident_per_cu(spec->nv)) h->grid = h->num_cu * n;
   }
+#endif
   h->slab_doubles = slab_doubles(spec);
 #ifdef CMPC_PROFILE
   if (hipMalloc(&h->prof, 28 * sizeof(long long)) == hipSuccess) (void)hipMemset(h->prof, 0, 28 * sizeof(long long));
 #endif
-  if (hipMalloc(&h->scratch, (size_t)h->grid * h->slab_doubles * sizeof(double)) != hipSuccess ||
+  if (hipMalloc(&h->scratch, (size_t)h->slabs * h->slab_doubles * sizeof(double)) != hipSuccess ||
       hipMalloc(&h->ticket, ORDER_COUNTERS * sizeof(int)) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess) {
     cmpc_destroy(h);
@@ -422,16 +449,23 @@ int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, cons
   hipLaunchKernelGGL(cmpc_order_score_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->spec.N, omega, h->spec.cz_max, params, state_in, nstate,
                      mu_word, h->order + B, h->ticket);
   hipLaunchKernelGGL(cmpc_order_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, h->order + B, h->order, h->ticket);
-  if (h->spec.nv == 4 && B <= h->pair_max_batch)     // the batch does not fill the GPU for long: two waves per instance
-  {
-    const dim3 pg(B < h->pair_grid ? B : h->pair_grid);
-    if (h->pair_per_cu >= 3) hipLaunchKernelGGL((cmpc_solve_pair_kernel<4, 2>), pg, dim3(128), 0, st, ka, h->ticket, h->order);
-    else hipLaunchKernelGGL((cmpc_solve_pair_kernel<4, 1>), pg, dim3(128), 0, st, ka, h->ticket, h->order);
-  }
-  else if (h->spec.nv == 4)
+  const bool pair = h->spec.nv == 4 && B <= h->pair_max_batch;   // the batch does not fill the GPU for long: two waves per instance
+  const int launch_grid = pair ? (B < h->pair_grid ? B : h->pair_grid) : grid;
+  if (launch_grid > h->slabs) return fail(h, "cmpc_solve_batch: launch grid exceeds the slabs of the handle");
+  if (pair) {
+    const dim3 pg(launch_grid);
+#ifdef CMPC_DEV_KNOBS
+    if (h->pair_per_cu < 3) { hipLaunchKernelGGL((cmpc_solve_pair_kernel<4, 1>), pg, dim3(128), 0, st, ka, h->ticket, h->order); h->last_kernel = "cmpc_solve_pair_kernel<4, 1>"; }
+    else
+#endif
+    { hipLaunchKernelGGL((cmpc_solve_pair_kernel<4, 2>), pg, dim3(128), 0, st, ka, h->ticket, h->order); h->last_kernel = "cmpc_solve_pair_kernel<4, 2>"; }
+  } else if (h->spec.nv == 4) {
     hipLaunchKernelGGL((cmpc_solve_kernel<4, 1>), dim3(grid), dim3(64), 0, st, ka, h->ticket, h->order);
-  else
+    h->last_kernel = "cmpc_solve_kernel<4, 1>";
+  } else {
     hipLaunchKernelGGL((cmpc_solve_kernel<8, cmpc::WAVES_NV8>), dim3(grid), dim3(64 * cmpc::WAVES_NV8), 0, st, ka, h->ticket, h->order);
+    h->last_kernel = "cmpc_solve_kernel<8, 2>";
+  }
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev1, st));
   h->timed = true;
@@ -520,8 +554,18 @@ int cmpc_build_records_planned(const cmpc_tables *tb, int32_t N, int32_t rate, i
   return 0;
 }
 
+const char *cmpc_last_kernel_name(cmpc_handle *h) { return h ? h->last_kernel : ""; }
 const char *cmpc_last_error(cmpc_handle *h) { return h ? h->err.c_str() : g_err.c_str(); }
-const char *cmpc_version(void) { return "cmpc_amd 0.4 (gfx950)"; }
+const char *cmpc_version(void) { return "cmpc_amd 0.5 (gfx950)"; }
+
+#ifdef CMPC_DEV_KNOBS
+/* developer build only: the first slab of the handle (the slab of workgroup 0), for dumps of a B = 1 launch */
+int cmpc_debug_slab(cmpc_handle *h, double **ptr, size_t *doubles) {
+  if (!h || !ptr || !doubles) return 1;
+  *ptr = h->scratch; *doubles = h->slab_doubles;
+  return 0;
+}
+#endif
 
 #ifdef CMPC_PROFILE
 /* diagnostic build only: read and reset the phase cycle sums */

@@ -20,6 +20,7 @@
 #pragma once
 #include "../../include/cmpc.h"
 #include <math.h>
+#include <utility>
 #ifdef CMPC_HOST_EMU
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,9 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 // across the whole solve and spilled)
 #define CMPC_OPAQUE(x) asm volatile("" : "+v"(x))
 #define CMPC_OPAQUE_D(x) asm volatile("" : "+v"(x))
+// nothing is scheduled across this point (keeps a batch of loads, its wait and its arithmetic together: left to itself
+// the scheduler parks the loaded words and spills them)
+#define CMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // the lane id again from the execution mask (two instructions): where it is re-derived the old value need not stay
 // live -- or be spilled -- across the code in front (one wave per workgroup: lane id = thread id)
 #define CMPC_RELANE(x) do { (x) = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) + lane_base; } while (0)
@@ -76,6 +80,12 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 #ifndef CMPC_RELANE
 #define CMPC_RELANE(x) do { } while (0)
 #endif
+// x * y + z in ONE rounding, spelled out.  Everywhere else the multiply-adds are formed by the compiler's contraction of
+// a * b + c, whose choices depend on the code around (which product is hoisted out of a masked block, which sum is
+// restarted at a neighbouring add): fine for code both solver kernels share verbatim, not for G'PG, which the single wave
+// and the pair reach in different orders and must still form bit for bit alike.  (The host emulation is built with
+// -mfma -ffp-contract=off: the same fused operations, nothing else fused.)
+#define CMPC_FMA(x, y, z) __builtin_fma((x), (y), (z))
 #ifndef CMPC_OPAQUE_D
 #define CMPC_OPAQUE_D(x) do { } while (0)
 #endif
@@ -166,7 +176,8 @@ template <int CNT> CMPC_DEV void lds_read_row(double (&v)[CNT], const double *p)
 }
 #endif
 
-template <int NV, int NW = 1> struct Dims {
+// Sizes of the stage block of a solver (NV contact vertices per foot, NW waves per instance).
+template <int NV, int NW> struct Sizes {
   static_assert(NW == 1 || NW == 2, "one or two waves per instance");
   static constexpr int WS = 64 * NW;          // lanes of the workgroup that owns an instance
   static constexpr int NF = 2 * NV;           // contact vertices
@@ -178,70 +189,145 @@ template <int NV, int NW = 1> struct Dims {
   static constexpr int NH = (NZ + WS - 1) / WS;   // rows / columns of the stage block owned by one lane
   static constexpr int PS = NXA + 1;          // odd row strides: conflict-free column access
   static constexpr int LS = NU + 1;
-  // T = P [B A] is staged in NPART column parts.  One wave, 60 columns: three parts of 20 columns, and the lanes of the
-  // wave are (column of the part) x (row third), so that all 64 lanes work on every part; otherwise halves.
-  static constexpr int NPART = (NV == 4 && NW == 1) ? 3 : 2;
-  static constexpr int TH = (NZ + NPART - 1) / NPART;   // columns per part
-  static constexpr int TS = TH | 1;
-  // ---- LDS map (doubles) ----
-  static constexpr int oM = 0;
-  static constexpr int oP = oM + NTRI + (NTRI & 1);
-  // P_{k+1}: the full symmetric array (row stride PS) or, for the one-wave 4-vertex solver, its packed lower triangle
-  // (406 words instead of 812: a column read then takes both candidate words of every element and a select)
-  static constexpr bool P_PACKED = (NV == 4 && NW == 1);
   static constexpr int NPT = NXA * (NXA + 1) / 2;
-  static constexpr int P_DOUBLES = P_PACKED ? NPT + (NPT & 1) : NXA * PS + ((NXA * PS) & 1);
-  // After M and P: first what stays live from a stage's evaluation to its backward vectors, then the evaluation
-  // vectors in the order that lets the T tile (which aliases them where it fits) end before GH.  Sizes in the compact
-  // form (one-wave 4-vertex solver: six workgroups per CU need the whole image under 26 880 bytes) are exact.
-  static constexpr bool COMPACT = (NV == 4 && NW == 1);
-  static constexpr int DUMPN = COMPACT ? 16 : WS;              // write-only slots for masked-off stores (lane & (DUMPN - 1))
-  static constexpr int MISCN = COMPACT ? 52 : 64;              // scalars of the geometry / inequality phases (0 .. 49 used)
+};
+
+// ---- LDS map (doubles), 8-vertex solver (one or two waves): M, the full symmetric P, the stage vectors, and a staging tile
+// of T = P [B A] in two column halves behind them.
+template <int NV, int NW, bool PIPE> struct LdsMap : Sizes<NV, NW> {
+  using S = Sizes<NV, NW>;
+  static constexpr bool GT = false, GT_FIRST = false;
+  static constexpr int NPART = 2;
+  static constexpr int TH = (S::NZ + NPART - 1) / NPART;   // columns per part
+  static constexpr int TS = TH | 1;
+  static constexpr int oM = 0;
+  static constexpr int oP = oM + S::NTRI + (S::NTRI & 1);
+  static constexpr bool P_PACKED = false;
+  static constexpr int P_DOUBLES = S::NXA * S::PS + ((S::NXA * S::PS) & 1);
+  static constexpr int DUMPN = S::WS;                          // write-only slots for masked-off stores (lane & (DUMPN - 1))
+  static constexpr int MISCN = 64;                             // scalars of the geometry / inequality phases (0 .. 49 used)
   static constexpr int oXN1 = oP + P_DOUBLES;                  // v0 = p_{k+1} + P_{k+1} b
-  static constexpr int oSR = oXN1 + NXA;      // stage record k (19), k-1 (19), header (24)
+  static constexpr int oSR = oXN1 + S::NXA;   // stage record k (19), k-1 (19), header (24)
   static constexpr int oSRP = oSR + 20;
   static constexpr int oHDR = oSRP + 20;
   static constexpr int oH0 = oHDR + 24;       // gradient parts h = h0 + mu*h1 of the stage (NZ each)
-  static constexpr int oH1 = oH0 + NZ;
-  static constexpr int oPC1 = oH1 + NZ;       // mu-coefficient of the cost-to-go gradient (NXA)
-  static constexpr int oRED = oPC1 + NXA;     // 4 scratch slots
+  static constexpr int oH1 = oH0 + S::NZ;
+  static constexpr int oPC1 = oH1 + S::NZ;    // mu-coefficient of the cost-to-go gradient (NXA)
+  static constexpr int oRED = oPC1 + S::NXA;  // 4 scratch slots
   static constexpr int oCOLD = oRED + 4;      // outer-loop state that is touched once per iteration (8 scalars): kept here
                                               // instead of in registers, where it was spilled to scratch
   static constexpr int oDUMP = oCOLD + 8;
   // ---- evaluation vectors: dead from the end of the gradient (the P b product for BV / PC) to the next stage's load
   static constexpr int oXK = oDUMP + DUMPN + ((oDUMP + DUMPN) & 1);
-  static constexpr int oUK = oXK + NXA;
-  static constexpr int oLAMK = oUK + NU;
-  static constexpr int oLAMN = oLAMK + NXA;
-  static constexpr int oUPX = oLAMN + NXA;
-  static constexpr int oSK = oUPX + NU;
-  static constexpr int oZK = oSK + NI;
-  static constexpr int oGK = oZK + NI;
-  static constexpr int oW0 = oGK + NI;        // sigma = z/s
-  static constexpr int oW1 = oW0 + NI;        // sigma*(g+s)
-  static constexpr int oW2 = oW1 + NI;        // 1/s
-  static constexpr int oVDV = oW2 + NI;       // R' v_j (NF x 3)
-  static constexpr int oMISC = oVDV + 3 * NF;
+  static constexpr int oUK = oXK + S::NXA;
+  static constexpr int oLAMK = oUK + S::NU;
+  static constexpr int oLAMN = oLAMK + S::NXA;
+  static constexpr int oUPX = oLAMN + S::NXA;
+  static constexpr int oSK = oUPX + S::NU;
+  static constexpr int oZK = oSK + S::NI;
+  static constexpr int oGK = oZK + S::NI;
+  static constexpr int oW0 = oGK + S::NI;     // sigma = z/s
+  static constexpr int oW1 = oW0 + S::NI;     // sigma*(g+s)
+  static constexpr int oW2 = oW1 + S::NI;     // 1/s
+  static constexpr int oVDV = oW2 + S::NI;    // R' v_j (NF x 3)
+  static constexpr int oMISC = oVDV + 3 * S::NF;
   static constexpr int oAL = oMISC + MISCN;   // Lyapunov gradient (NZ); second temporary of the backward vectors
-  static constexpr int oGH = oAL + NZ;        // rows 6..8 of [B A] without identity (3 x NZ)
-  static constexpr int oBV = oGH + 3 * NZ;
-  static constexpr int oPC = oBV + NXA;
-  static constexpr int oEND = oPC + NXA;
+  static constexpr int oGH = oAL + S::NZ;     // rows 6..8 of [B A] without identity (3 x NZ)
+  static constexpr int oBV = oGH + 3 * S::NZ;
+  static constexpr int oPC = oBV + S::NXA;
+  static constexpr int oEND = oPC + S::NXA;
   // overlays: r_j (NF x 3) lives from the first to the third step of the geometry, in the words the inequality rows
-  // then fill with the Lyapunov gradient; the NZ-word temporary of the backward vectors takes the slacks' place
+  // then fill with the Lyapunov gradient; the two NZ-word temporaries of the backward vectors take the slacks' and the
+  // Lyapunov gradient's place
   static constexpr int oVR = oAL;
   static constexpr int oTV = oSK;
-  static_assert(3 * NF <= NZ && NZ <= 2 * NI, "overlays fit");
-  // The staging tile of T = P [B A] (NXA x TS): for nv = 4 it aliases the evaluation vectors from their start and ends
-  // before GH, which the parts' column lists are rebuilt from; for nv = 8 it gets its own region.
-  static constexpr bool T_ALIAS = (NV == 4);
-  static constexpr int oT = T_ALIAS ? oXK : oEND;
-  static_assert(!T_ALIAS || oT + (NXA - 1) * TS + TH <= oGH, "the T tile ends before the dense rows of [B A]");
+  static constexpr int oTV2 = oAL;
+  static_assert(3 * S::NF <= S::NZ && S::NZ <= 2 * S::NI, "overlays fit");
+  static constexpr int oT = oEND;             // the staging tile of T = P [B A] (NXA x TS)
+  static constexpr int oUB = oT;              // in-block multiplier table of the factorisation (the T tile is dead there)
   static_assert(oT % 2 == 0, "16-byte reads of the in-block table");
   // (+ T_PAD: add_GtPG reads the T rows in batches of 10 columns whatever the row's length; the tail of the
   // last row must still be inside the allocation)
   static constexpr int T_PAD = 10;
-  static constexpr int LDS_DOUBLES = T_ALIAS ? oEND : oEND + NXA * TS + T_PAD;
+  static constexpr int LDS_DOUBLES = oEND + S::NXA * TS + T_PAD;
+};
+
+// ---- LDS map (doubles), one-wave 4-vertex solver (round 5).  T = P [B A] is held one column per lane in REGISTERS and
+// M (+)= [B A]' T is formed column-per-lane from it (Solver::gt_phase), so there is no staging tile; P is a packed
+// triangle.  The single wave forms G'PG BEFORE the Hessian rows (GT_FIRST): P_{k+1} is dead after the T columns are in
+// registers, i.e. from early in a stage until its factorisation writes P_k, and M is dead from the factor store of stage
+// k + 1 until stage k's G'T is written.  What is born and dies inside those windows is overlaid on the two regions:
+//   in M (dead: load ... T phase):   GH, BV, r_j        (geometry -> column lists / P b / T phase)
+//   in P (dead: T phase ... factor): AL, GK, W0, W1, W2 (inequality rows -> gradient)
+// 2866 doubles = 22 928 bytes: SEVEN workgroups per CU (1280-byte granules: <= 23 040).  The pipelined pair (PIPE) keeps
+// the Hessian rows first -- its evaluating wave runs a stage ahead of the cost-to-go -- and nothing of it is overlaid
+// (two images, three pairs per CU as before).
+template <bool PIPE> struct LdsMap<4, 1, PIPE> : Sizes<4, 1> {
+  using S = Sizes<4, 1>;
+#ifdef CMPC_NO_GT_FIRST                          // (diagnostic build: the single wave in the pair's order, Hessian rows first)
+  static constexpr bool GT = true, GT_FIRST = false;
+#else
+  static constexpr bool GT = true, GT_FIRST = !PIPE;
+#endif
+  static constexpr int oM = 0;
+  static constexpr int oP = oM + S::NTRI + (S::NTRI & 1);
+  static constexpr bool P_PACKED = true;
+  static constexpr int P_DOUBLES = S::NPT + (S::NPT & 1);
+  static constexpr int DUMPN = 16;
+  static constexpr int MISCN = 52;
+  // live across a whole stage
+  static constexpr int oXN1 = oP + P_DOUBLES;
+  static constexpr int oSR = oXN1 + S::NXA;
+  static constexpr int oSRP = oSR + 20;
+  static constexpr int oHDR = oSRP + 20;
+  static constexpr int oH0 = oHDR + 24;
+  static constexpr int oH1 = oH0 + S::NZ;
+  static constexpr int oPC1 = oH1 + S::NZ;
+  static constexpr int oPC = oPC1 + S::NXA;
+  static constexpr int oRED = oPC + S::NXA;
+  static constexpr int oCOLD = oRED + 4;
+  static constexpr int oDUMP = oCOLD + 8;
+  // from the stage's loads to its gradient
+  static constexpr int oXK = oDUMP + DUMPN + ((oDUMP + DUMPN) & 1);
+  static constexpr int oUK = oXK + S::NXA;
+  static constexpr int oLAMK = oUK + S::NU;
+  static constexpr int oLAMN = oLAMK + S::NXA;
+  static constexpr int oUPX = oLAMN + S::NXA;
+  static constexpr int oSK = oUPX + S::NU;
+  static constexpr int oZK = oSK + S::NI;
+  static constexpr int oVDV = oZK + S::NI;
+  static constexpr int oMISC = oVDV + 3 * S::NF;
+  static constexpr int oLATE = oMISC + MISCN;                  // end of what every variant keeps of its own
+  // inequality rows -> gradient: AL, GK, W0, W1, W2
+  static constexpr int LATE_DOUBLES = S::NZ + 4 * S::NI;
+  static constexpr int oAL = GT_FIRST ? oP : oLATE;
+  static constexpr int oGK = oAL + S::NZ;
+  static constexpr int oW0 = oGK + S::NI;
+  static constexpr int oW1 = oW0 + S::NI;
+  static constexpr int oW2 = oW1 + S::NI;
+  static_assert(!GT_FIRST || LATE_DOUBLES <= P_DOUBLES, "the late evaluation vectors fit the dead P region");
+  // geometry -> T phase: GH, BV, r_j
+  static constexpr int oGH = GT_FIRST ? oM : oLATE + LATE_DOUBLES;
+  static constexpr int oBV = oGH + 3 * S::NZ;
+  static constexpr int oVR = GT_FIRST ? oBV + S::NXA : oAL;   // (PIPE: in the words the inequality rows then fill, as before)
+  static constexpr int oEND = GT_FIRST ? oLATE : oBV + S::NXA;
+  // temporaries of the backward vectors (NZ words each), in-block multiplier table of the factorisation (64 words):
+  // all in evaluation vectors that are dead by then
+  static constexpr int oTV = oSK;
+  static constexpr int oTV2 = oXK;
+  static constexpr int oUB = oSK;
+  static_assert(oTV2 + S::NZ <= oLAMK && oTV + S::NZ <= oVDV && oUB + 64 <= oVDV && oUB % 2 == 0, "temporaries fit");
+  static_assert(3 * S::NF <= S::NZ, "r_j fits");
+  static constexpr int LDS_DOUBLES = oEND + (oEND & 1);
+  static constexpr int NPART = 1, TH = S::NZ, TS = S::NZ | 1, oT = oUB, T_PAD = 0;   // (no staging tile; names kept for shared code)
+};
+
+template <int NV, int NW = 1, bool PIPE = false> struct Dims : LdsMap<NV, NW, PIPE> {
+  using S = Sizes<NV, NW>;
+  using Lm = LdsMap<NV, NW, PIPE>;
+  static constexpr int WS = S::WS, NF = S::NF, NU = S::NU, NXA = S::NXA, NZ = S::NZ, NI = S::NI, NTRI = S::NTRI, NH = S::NH,
+                       PS = S::PS, LS = S::LS, NPT = S::NPT;
+  static constexpr bool COMPACT = (NV == 4 && NW == 1);
   // ---- global scratch map per stage (doubles) ----
   // The factorised stage block as it stands in LDS, a packed lower triangle of NZ rows, copied word for word:
   // rows 0..NU-1 hold Lambda, row NU+c holds [Ls row c | P_k row c up to the diagonal].  (Round 2 wrote Lambda as a
@@ -299,7 +385,7 @@ struct GArr {
 // order as the single wave: results are bit for bit those of Solver<NV, 1>.  For batches that do not fill the GPU (the
 // reference's own use is ONE instance per tick, code/simulation.py:203-204): an instance finishes ~1.4x sooner.
 template <int NV, int NW = 1, bool PIPE = false> struct Solver {
-  using D = Dims<NV, NW>;
+  using D = Dims<NV, NW, PIPE>;
   // PIPE: words behind the two LDS images.  [0..5] error measures, [6] ap, [7] ad, [8..9] factorisation verdict of the
   // sweep step in hand (by step parity), [16 ..): du_k of the forward sweep by stage parity (read by the slack wave)
   static constexpr int XCH_DU = 16, XCH_DOUBLES = XCH_DU + 2 * D::NU;
@@ -308,6 +394,10 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   static_assert(!PIPE || XCH_DOUBLES <= D::P_DOUBLES, "the exchange words fit in the unused P region of the second image");
   static constexpr int XCH_AT = D::LDS_DOUBLES + D::oP;
   static_assert(!PIPE || NW == 1, "the pipelined pair runs the one-wave solver");
+  // PIPE: while wave 0 runs riccati_stage(k - 1) in the other image (G'PG out of registers, the factorisation with its
+  // in-block table), wave 1's pair_vectors(k) reads that image's BV and writes its XN1: the table must not touch them.
+  static_assert(!PIPE || (D::oUB + 64 <= D::oBV && D::oUB >= D::oXN1 + D::NXA && !D::GT_FIRST),
+                "pair_vectors reads BV / writes XN1 of the image the Riccati wave is working in");
   static constexpr int NF = D::NF, NU = D::NU, NXA = D::NXA, NZ = D::NZ, NI = D::NI, NH = D::NH, WS = D::WS;
   static_assert(NW == 1 || NU <= 64, "the input rows (pivot chains, substitutions) live in the first wave");
 
@@ -730,14 +820,22 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   // Row `lane` of the Lagrangian Hessian + barrier terms into the packed lower triangle M.
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void build_H(int k, double reg, double wz) {
+#ifdef CMPC_DEBUG_SKIP_H                       // (diagnostic build: G'PG alone in M)
+    if constexpr (!D::GT_FIRST) { for (int e = lane; e < D::NTRI; e += WS) L(D::oM + e) = 0.0; }
+    sync();
+    return;
+#endif
 #pragma unroll 1
     for (int h_ = 0; h_ < NH; ++h_) build_H_row(k, reg, wz, lane + WS * h_);
   }
   // One pass over the columns, the same instruction stream for every row: the column type (force
   // axis / foot, velocity, state group) is wave-uniform, everything that depends on the row is a
   // per-lane coefficient computed up front, and entries right of the diagonal are redirected to the
-  // lane's dump slot instead of being branched around.  No LDS read-modify-write, no zero fill.
+  // lane's dump slot instead of being branched around.  No LDS read-modify-write, no zero fill -- except for the single
+  // wave of the 4-vertex solver (D::GT_FIRST), where M already holds [B A]' P [B A] and the row ADDS its non-zero
+  // columns to it (the old values of a column group come in one batch; the structurally zero columns are not touched).
   CMPC_DEV void build_H_row(int k, double reg, double wz, const int irow) {
+    constexpr bool RMW = D::GT_FIRST;
     const bool live = irow < NZ;
     const int i = live ? irow : 0;              // idle lanes shadow row 0 and write only to the dump slot
     const int wlim = live ? i : 0;              // columns j < wlim are written
@@ -858,6 +956,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       else { lds_read_strided28<1>(alf, al + f * FC); lds_read_strided28<1>(dvv, &L(D::oVDV + f * FC)); }
       const double cf0 = cst[f][0], cf1 = cst[f][1], cf2 = cst[f][2];
       const double gmf = gm[f];
+      double oldf[14];
+      if constexpr (RMW) { static_assert(!RMW || FC <= 14, "one batch"); lds_read_strided14<1>(oldf, row + FC * f); }
 #pragma unroll
       for (int vv = 0; vv < NV; ++vv) {
         const double dvx = dvv[3 * vv], dvy = dvv[3 * vv + 1];
@@ -867,19 +967,26 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
           double val = sA * alf[3 * vv + a] + ((a == 0) ? cf0 : (a == 1) ? cf1 : cf2) + gmf * (ccx[a] * dvx + ccy[a] * dvy);
           if (a < 2) val += (j == j_fr0 + a) ? ((a == 0) ? fr0 : fr1) : 0.0;
           if (a == 2) val += (j == j_fp) ? -2 * wr_fp : 0.0;
+          // (opaque: the row's own entry is rounded before the old value is added, as it is where the Hessian rows are
+          // written first and G'PG added to them -- the pair; a product fused into this sum would differ in the last bit)
+          if constexpr (RMW) { CMPC_OPAQUE_D(val); val += oldf[(3 * vv + a) % 14]; }
           *((j < wlim) ? row + j : dump) = val;
         }
       }
     }
     CMPC_TICK(15);
     // ---- foot velocity columns: proximal term only ----
+    if constexpr (!RMW) {
 #pragma unroll
-    for (int j = 6 * NV; j < NU; ++j) *((j < wlim) ? row + j : dump) = 0.0;
+      for (int j = 6 * NV; j < NU; ++j) *((j < wlim) ? row + j : dump) = 0.0;
+    }
     // ---- state columns ----
     const bool hwc_row = (k == 1) && is_state && s >= 6 && s < 9;
     const double hwc_c = hwc_row ? 4 * sig[R_HWC] * x[(s >= 6 && s < 9) ? s : 6] : 0.0;
     double als[14];                             // al / x of the 12 leading state columns (c, v, hw, theta)
     lds_read_strided14<1>(als, al + NU);
+    double olds[14];
+    if constexpr (RMW) lds_read_strided14<1>(olds, row + NU);
 #pragma unroll
     for (int sj = 0; sj < 12; ++sj) {
       const int j = NU + sj;
@@ -888,10 +995,13 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       if (tj >= 0) {
         val = sA * als[sj] + ((aj == ai) ? zq[tj] : 0.0);
       } else val = hwc_c * x[sj];
+      if constexpr (RMW) { CMPC_OPAQUE_D(val); val += olds[sj]; }
       *((j < wlim) ? row + j : dump) = val;
     }
+    if constexpr (!RMW) {
 #pragma unroll 4
-    for (int j = NU + 12; j < NZ; ++j) *((j < wlim) ? row + j : dump) = 0.0;
+      for (int j = NU + 12; j < NZ; ++j) *((j < wlim) ? row + j : dump) = 0.0;
+    }
     CMPC_TICK(23);
     // ---- diagonal ----
     // Lyapunov part: the (i, i) entry of the rank-1 term and of the multiplier-weighted constant Hessian
@@ -908,7 +1018,130 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     diag += (kp && is_fp && stage) ? 2 * wr_fp : 0.0;
     diag += (ctype == 3) ? q30 : 0.0;
     diag = is_state ? diag : (stage ? diag + sp.prox : reg + 1.0);   // no inputs at the terminal node
+    if constexpr (RMW) { CMPC_OPAQUE_D(diag); diag += row[i]; }
     if (live) row[i] = diag;
+  }
+
+  // ---------------------------------------------------------------------------------------
+  // G'PG of the one-wave 4-vertex solver (round 5): no staging tile, no gathered reads of T.
+  //   T phase.  Lane j forms column j of T = P_{k+1} [B A] in NXA registers: its column list (<= 6 entries) times the
+  //   list's columns of the packed triangle of P.  Word (q, c) of the triangle sits at tri(max(q, c)) + min(q, c) =
+  //   max(tri(c), c + tri(q - 1)) + q: one v_add and one v_max per word for the per-lane part, the `+ q` in the
+  //   instruction's immediate (rounds 3-4: both forms computed and selected, four instructions per word).
+  //   M phase.  (G'T)[i][j] = sum_n g_i[n] T[r_i[n]][j]: with column j of T in lane j's registers, row i of the product is
+  //   the same handful of multiply-adds in every lane -- the rows r_i[n] are compile-time constants of the column
+  //   structure of [B A] (the loop over i is unrolled), the coefficients g_i[n] are wave-uniform: the three dense rows'
+  //   entries gh[.][i] are broadcast from lane i's own list by v_readlane (scalar operands of the multiply-adds), the
+  //   others are five scalars of the stage.  Structural zeros cost nothing.  Row i of the packed M is then one coalesced write (RMW = false: the single wave forms G'PG before the
+  //   Hessian rows, which add themselves to it) or read-modify-write (the pair: Hessian rows first) by lanes j <= i.
+  //   Rounds 1-4 staged T in LDS in three column parts and accumulated M row-owner from gathered T rows: ~600 LDS and
+  //   ~1700 vector-ALU instructions per stage, against ~350 and ~800 here.
+  // ---------------------------------------------------------------------------------------
+  template <int I> static constexpr bool gt_dense() {               // column I of [B A] has entries in the three dense rows
+    constexpr int s = I - NU;
+    return I < 6 * NV || (I >= NU && (s < 3 || s == 12 || s == 16 || (s >= 13 && s < 16) || (s >= 17 && s < 20)));
+  }
+  template <int I> CMPC_DEV double gt_row(const double (&tc)[D::NXA], const double (&cf)[2], const double (&cv)[2],
+                                          double ck, double cd, double cdm) const {
+    // same entries, same order as column_list(I): identity, the three dense rows, the two specials
+    double v = 0.0;
+    constexpr bool is_f = I < 6 * NV, is_vel = I >= 6 * NV && I < 6 * NV + 6, is_om = I >= 6 * NV + 6 && I < NU;
+    constexpr int s = I - NU;
+    if constexpr (I >= NU && s < CMPC_NX) v = tc[s];
+    if constexpr (gt_dense<I>()) {
+      // (lane I holds the column's dense entries in its list: two v_readlane per word, no LDS)
+      const double g0 = CMPC_BCAST(lg[0][1], I), g1 = CMPC_BCAST(lg[0][2], I), g2 = CMPC_BCAST(lg[0][3], I);
+      v = CMPC_FMA(g0, tc[6], v); v = CMPC_FMA(g1, tc[7], v); v = CMPC_FMA(g2, tc[8], v);
+    }
+    if constexpr (is_f) {
+      constexpr int vtx = I / 3, a = I % 3, f = vtx / NV;
+      v = CMPC_FMA(cf[f], tc[3 + a], v);
+      if constexpr (a == 2) v = v + tc[CMPC_NX + vtx];
+    } else if constexpr (is_vel) {
+      constexpr int f = (I - 6 * NV) / 3, a = (I - 6 * NV) % 3;
+      v = CMPC_FMA(cv[f], tc[13 + 4 * f + a], v);
+    } else if constexpr (is_om) {
+      constexpr int f = I - 6 * NV - 6;
+      v = CMPC_FMA(cv[f], tc[12 + 4 * f], v);
+    } else if constexpr (s < 3) {
+      v = CMPC_FMA(ck, tc[9 + s], v);
+    } else if constexpr (s < 6) {
+      v = CMPC_FMA(cd, tc[s - 3], v); v = CMPC_FMA(cdm, tc[9 + s - 3], v);
+    }
+    return v;
+  }
+  template <int I0, int... R> CMPC_DEV void gt_vals(std::integer_sequence<int, R...>, double (&val)[sizeof...(R)],
+                                                    const double (&tc)[D::NXA], const double (&cf)[2], const double (&cv)[2],
+                                                    double ck, double cd, double cdm) const {
+    ((val[R] = gt_row<I0 + R>(tc, cf, cv, ck, cd, cdm)), ...);
+  }
+  static constexpr int GT_ROWS = 12;           // rows of M per batch (RMW: their old values come in one batch of LDS reads)
+  template <bool RMW, int... G> CMPC_DEV void gt_groups(std::integer_sequence<int, G...>, const double (&tc)[D::NXA],
+                                                        const double (&cf)[2], const double (&cv)[2], double ck, double cd, double cdm) {
+    (gt_rows<RMW, GT_ROWS * G>(tc, cf, cv, ck, cd, cdm), ...);
+  }
+  template <bool RMW, int I0> CMPC_DEV void gt_rows(const double (&tc)[D::NXA], const double (&cf)[2], const double (&cv)[2],
+                                                    double ck, double cd, double cdm) {
+    constexpr int CNT = GT_ROWS;
+    double *M = &L(D::oM);
+    double val[CNT], old[CNT];
+    if constexpr (RMW) lds_read_tri12<I0>(old, M + lane);                   // M[tri(I0 + r) + lane] (right of the diagonal: a harmless word)
+    gt_vals<I0>(std::make_integer_sequence<int, CNT>{}, val, tc, cf, cv, ck, cd, cdm);
+#pragma unroll
+    for (int r = 0; r < CNT; ++r) {
+      if constexpr (RMW) CMPC_OPAQUE_D(val[r]);              // (rounded before the add, as where it is stored first: see build_H_row)
+      if (lane <= I0 + r) M[tri(I0 + r) + lane] = RMW ? old[r] + val[r] : val[r];
+    }
+    CMPC_SCHED_FENCE();
+  }
+  template <bool RMW> CMPC_DEV void gt_phase(double gl, double gr, double m) {
+    static_assert(D::GT && NH == 1 && NXA == 28 && NZ % GT_ROWS == 0, "one-wave 4-vertex solver");
+    double tc[NXA];
+#pragma unroll
+    for (int q = 0; q < NXA; ++q) tc[q] = 0.0;
+    {
+      const double *Pp = &R(D::oP);
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        const double g = lg[0][n];
+        const int c = lr[0][n];
+        // word (q, c) of the packed triangle = P + max(tri(c), c + tri(q - 1)) + q
+        const cmpc_lds_word wt = cmpc_lds_word_at(Pp, tri(c)), wc = cmpc_lds_word_at(Pp, c);
+#pragma unroll
+        for (int q0 = 0; q0 < NXA; q0 += 14) {
+          double v[14];
+          if (n >= 1 && n <= 3) {
+            // the three dense rows: the same column 6, 7, 8 of P in every lane -- uniform addresses, all of them immediates
+            if (n == 1) { if (q0 == 0) lds_read_pcol14<6, 0>(v, Pp); else lds_read_pcol14<6, 14>(v, Pp); }
+            else if (n == 2) { if (q0 == 0) lds_read_pcol14<7, 0>(v, Pp); else lds_read_pcol14<7, 14>(v, Pp); }
+            else { if (q0 == 0) lds_read_pcol14<8, 0>(v, Pp); else lds_read_pcol14<8, 14>(v, Pp); }
+          } else {
+            cmpc_lds_word a[14];
+#pragma unroll
+            for (int q = 0; q < 14; ++q) {
+              const cmpc_lds_word alt = wc + CMPC_LDS_WORDS(tri(q0 + q - 1));
+              a[q] = (wt > alt) ? wt : alt;
+            }
+            if (q0 == 0) lds_read_gather_off14<0>(v, a); else lds_read_gather_off14<14>(v, a);
+          }
+#pragma unroll
+          for (int q = 0; q < 14; ++q) { tc[q0 + q] = CMPC_FMA(g, v[q], tc[q0 + q]); CMPC_OPAQUE_D(tc[q0 + q]); }   // (opaque: the multiply-adds stay here
+          CMPC_SCHED_FENCE();                  //  instead of being sunk to the M phase with the loaded words kept -- and spilled -- until then)
+        }
+      }
+    }
+    if constexpr (D::GT_FIRST) sync();         // every lane has read its words of P: the region is free for the late vectors
+    CMPC_TICK(10);
+    const double d = sp.delta;
+    const double cf[2] = {d * gl / m, d * gr / m}, cv[2] = {d * (1 - gl), d * (1 - gr)};
+    const double ck = d * sp.k1 / m, cd = d, cdm = d / m;
+#ifdef CMPC_DEBUG_SKIP_GT                      // (diagnostic build: the Hessian rows alone in M)
+    if constexpr (!RMW) { for (int e = lane; e < D::NTRI; e += WS) L(D::oM + e) = 0.0; }
+#else
+    gt_groups<RMW>(std::make_integer_sequence<int, NZ / GT_ROWS>{}, tc, cf, cv, ck, cd, cdm);
+#endif
+    sync();
+    CMPC_TICK(14);
   }
 
   // M += [B A]' P [B A]  (lower triangle, row owner), using T = P [B A] staged by column halves.
@@ -922,48 +1155,6 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
 #pragma unroll 1
     for (int half = 0; half < D::NPART; ++half) {
       const int c0 = half * D::TH, c1 = (c0 + D::TH < NZ) ? c0 + D::TH : NZ;
-      if constexpr (D::NPART == 3) {
-        // lane = (column of the part, row third): rows 0..9, 10..19, 18..27 (the overlap is written twice with the
-        // same values); the column's list is rebuilt on the spot (the lane's own list is another column's)
-        static_assert(D::NPART != 3 || (3 * D::TH <= 64 && NXA == 28), "three row thirds of ten rows");
-        const int rs = (lane >= 2 * D::TH) ? 2 : (lane >= D::TH) ? 1 : 0;
-        const int col = c0 + lane - rs * D::TH, q0 = (rs == 2) ? NXA - 10 : 10 * rs;
-        if (lane < 3 * D::TH && col < c1) {
-          int cr[6];
-          double cg[6];
-          column_list(col, cr, cg, &L(D::oGH), gl, gr, m);
-          double acc[10];
-#pragma unroll
-          for (int q = 0; q < 10; ++q) acc[q] = 0.0;
-          const int tq0 = (rs == 2) ? tri(NXA - 10) : (rs == 1) ? tri(10) : 0;
-          int offq[10];
-#pragma unroll
-          for (int q = 0; q < 10; ++q) offq[q] = q * q0 + tri(q);
-#pragma unroll
-          for (int n = 0; n < 6; ++n) {
-            const double g = cg[n];
-            double v[10];
-            if constexpr (D::P_PACKED) {
-              // column c of the packed triangle, rows q0 .. q0 + 9: row <= c sits in row c of the triangle (contiguous),
-              // row >= c in its own row at column c.  The form is chosen on the address (one read per word): offq[q]
-              // = tri(q0 + q) - tri(q0) is per lane and shared by the six entries.
-              const int c = cr[n], t = c - q0;
-              const int ia = tri(c) + q0, ib = tq0 + c;
-              cmpc_lds_word pb[10];
-#pragma unroll
-              for (int q = 0; q < 10; ++q) pb[q] = cmpc_lds_word_at(&R(D::oP), (q <= t) ? ia + q : ib + offq[q]);
-              lds_read_gather10(v, pb);
-            } else {
-              lds_read_strided10<D::PS>(v, &R(D::oP + q0 * D::PS + cr[n]));
-            }
-#pragma unroll
-            for (int q = 0; q < 10; ++q) acc[q] += g * v[q];
-          }
-          double *tc = &L(D::oT + q0 * D::TS + (col - c0));
-#pragma unroll
-          for (int q = 0; q < 10; ++q) tc[q * D::TS] = acc[q];
-        }
-      }
       auto t_rows = [&](const int col, const int q0, const int *cr, const double *cg) {   // T[q0 .. q0+QT)[col]
         double acc[QT];
 #pragma unroll
@@ -983,8 +1174,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
 #pragma unroll
         for (int q = 0; q < QT; ++q) tc[q * D::TS] = acc[q];
       };
-      if constexpr (D::NPART == 3) {
-      } else if constexpr (NW == 1) {
+      if constexpr (NW == 1) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {         // column of T = P [B A] owned by this lane in this half
           const int col = lane + WS * h;
@@ -996,7 +1186,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       } else {
         // two waves: lane l of either wave takes column c0 + l of the half, the first wave its upper QT rows and the
         // second the lower ones; the column's list is rebuilt on the spot (the lane's own list is another column's)
-        static_assert(NW == 1 || (!D::T_ALIAS && D::TH <= 64 && NXA == 2 * QT), "T has its own tile; one lane per column and row half");
+        static_assert(NW == 1 || (D::TH <= 64 && NXA == 2 * QT), "one lane per column and row half");
         const int col = c0 + (lane & 63);
         if (col < c1) {
           int cr[6];
@@ -1120,7 +1310,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       if constexpr (NW > 1) {
         // the second wave's rows are "further rows": the first wave hands it the panel's reciprocals and
         // multipliers (and the pivot verdict) through eleven LDS words behind the in-block table of the T tile
-        double *pk = &L(D::oT + 64);
+        double *pk = &L(D::oUB + 64);
         if (lane == 0) {
           pk[0] = ok ? 1.0 : 0.0; pk[1] = i0; pk[2] = i1; pk[3] = i2; pk[4] = i3;
           pk[5] = t10; pk[6] = t20; pk[7] = t21; pk[8] = t30; pk[9] = t31; pk[10] = t32;
@@ -1150,7 +1340,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       // read back at wave-uniform addresses: one ds_read per pair of doubles on the LDS port instead of
       // four v_readlane on the vector ALU, which is what this phase is bound by.
       if (4 * p + 4 < W) {
-        double *ub = &L(D::oT);
+        double *ub = &L(D::oUB);
         {
           const int rr = lane - C0;            // row inside the block
           const bool src = rr >= 4 * p + 4 && rr < W;
@@ -1317,12 +1507,18 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       const int col = lane + WS * h;
       if (col >= NZ) continue;
       double a0 = L(D::oH0 + col), a1 = L(D::oH1 + col);
+      if constexpr (D::GT_FIRST) {
+        // (the single wave added [B A]' (p0 + P b) and [B A]' p1 when it had the lists in registers: eval_stage)
+      } else if constexpr (D::GT) {
+        a0 += list_dot(h, &L(D::oXN1)); a1 += list_dot(h, &R(D::oPC1));
+      } else {
 #pragma unroll
-      for (int n = 0; n < 6; ++n) {
-        a0 += lg[h][n] * L(D::oXN1 + lr[h][n]);
-        a1 += lg[h][n] * R(D::oPC1 + lr[h][n]);
+        for (int n = 0; n < 6; ++n) {
+          a0 += lg[h][n] * L(D::oXN1 + lr[h][n]);
+          a1 += lg[h][n] * R(D::oPC1 + lr[h][n]);
+        }
       }
-      L(D::oTV + col) = a0; L(D::oAL + col) = a1;
+      L(D::oTV + col) = a0; L(D::oTV2 + col) = a1;
     }
     sync();
     CMPC_TICK(2);
@@ -1331,7 +1527,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     double lf0, lf1;                           // l of this lane's row (lanes < NU)
     if (first_wave()) {                        // l = L^-1 m_u for both right-hand sides at once
       const int li = (lane < NU) ? lane : NU - 1;
-      double m0 = L(D::oTV + li), m1 = L(D::oAL + li);
+      double m0 = L(D::oTV + li), m1 = L(D::oTV2 + li);
       const double dinv = 1.0 / M[tri(li) + li];
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {         // own row of Lambda, half a row of registers at a time
@@ -1348,14 +1544,14 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       lf0 = m0 * dinv; lf1 = m1 * dinv;
       if (lane < NU) {
         st[D::gL + lane] = lf0; st[D::gL1 + lane] = lf1;
-        L(D::oTV + lane) = lf0; L(D::oAL + lane) = lf1;   // handed to the next step at wave-uniform LDS addresses
+        L(D::oTV + lane) = lf0; L(D::oTV2 + lane) = lf1;   // handed to the next step at wave-uniform LDS addresses
       }
     }
     sync();
     CMPC_TICK(3);
     if (first_wave()) {                        // p = m_x - Ls l
       const int lx = (lane < NXA) ? lane : 0;
-      const double *l0 = &L(D::oTV), *l1 = &L(D::oAL);
+      const double *l0 = &L(D::oTV), *l1 = &L(D::oTV2);
       double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
@@ -1380,7 +1576,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         }
       }
       if (lane < NXA) {
-        const double p0 = L(D::oTV + NU + lane) - (a0 + a1), p1 = L(D::oAL + NU + lane) - (b0 + b1);
+        const double p0 = L(D::oTV + NU + lane) - (a0 + a1), p1 = L(D::oTV2 + NU + lane) - (b0 + b1);
         R(D::oPC + lane) = p0; R(D::oPC1 + lane) = p1;
         st[D::gPV + lane] = p0; st[D::gPV1 + lane] = p1;
       }
@@ -1394,10 +1590,64 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   // (loads, geometry, inequality rows, barrier weights, Hessian rows, gradient; KKT error measures).  riccati_stage: the
   // part that does (P b, G'PG, factorisation, backward vectors, factor store); false on wrong inertia.  A single wave runs
   // them back to back; the pipelined pair runs eval_stage(k - 1) beside riccati_stage(k) on two LDS images.
+  // P b for the vector sweep: XN1 = p0_{k+1} + P_{k+1} b_k (lanes < NXA), b_k to the slab
+  CMPC_DEV void form_Pb(const GArr st) {
+    if (lane < NXA) {
+      const double *bv = &L(D::oBV);
+      double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+      if constexpr (D::P_PACKED) {
+        // row `lane` of the packed triangle: columns <= lane contiguous in the row, the others down column `lane`
+        static_assert(!D::P_PACKED || NXA == 28, "three batches of ten");
+        double pr[30];
+        {
+          const int tl = tri(lane);
+#pragma unroll
+          for (int q0 = 0; q0 < 30; q0 += 10) {
+            cmpc_lds_word pa[10];
+            double v[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+              const int qq = (q0 + q < NXA) ? q0 + q : NXA - 1;          // (the last batch repeats column 27 twice)
+              pa[q] = cmpc_lds_word_at(&R(D::oP), (qq <= lane) ? tl + qq : tri(qq) + lane);
+            }
+            lds_read_gather10(v, pa);
+#pragma unroll
+            for (int q = 0; q < 10; ++q) pr[q0 + q] = v[q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NXA; q += 4) {
+          b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
+        }
+      } else {
+        const double *pr = &R(D::oP + lane * D::PS);
+#pragma unroll
+        for (int q = 0; q < NXA; q += 4) {
+          b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
+        }
+      }
+      const double a = (b0 + b1) + (b2 + b3);
+      L(D::oXN1 + lane) = R(D::oPC + lane) + a;       // v0 = p0_{k+1} + P_{k+1} b
+      st[D::gB + lane] = L(D::oBV + lane);
+    }
+  }
+  // ([B A]' v)[col] for this lane's column: the list's entries summed from zero, in list order
+  CMPC_DEV double list_dot(int h, const double *v) const {
+    double a = 0.0;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) a = CMPC_FMA(lg[h][n], v[lr[h][n]], a);
+    // (opaque: where the caller adds this to something in the same basic block, hipcc's aggressive FMA fusion restarts
+    // the chain at that something -- fadd(x, fma(.., fmul)) -> fma(.., fma(.., x)) -- and the single wave, which parks the
+    // sum in LDS first, would differ from the pair in the last bit)
+    CMPC_OPAQUE_D(a);
+    return a;
+  }
+
   CMPC_DEV void eval_stage(int k, double mu, double reg, double wz, double x0n2, Err &er, bool init) {
     CMPC_RELANE(lane); CMPC_OPAQUE(lane);
     load_stage(k);
     CMPC_TICK(24);
+    const GArr st = stage(k);
     if (k < N) {
       stage_geometry(k);
     } else {
@@ -1406,6 +1656,30 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       sync();
     }
     CMPC_TICK(11);
+    double gl_dot[NH];                         // ([B A]' lam_{k+1})[col] of the dual residual
+    if constexpr (D::GT_FIRST) {
+      // The single wave forms G'PG here, before anything else of the stage needs LDS: GH, BV (in the dead M region) and
+      // P_{k+1} are consumed, after which the inequality rows' vectors take P's place and M holds [B A]' P [B A].  What the
+      // rest of the stage needs of the column lists is formed now, while they are in registers: [B A]' applied to
+      // lam_{k+1} (dual residual), to p0_{k+1} + P b and to p1_{k+1} (backward vectors; parked in H0 / H1, which the
+      // gradient later adds itself to).
+      if (k < N && lane < NXA) er.e_p = fmax(er.e_p, fabs(L(D::oBV + lane)));
+      build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
+      if (lane < NZ) { st[D::gGH + lane] = lg[0][1]; st[D::gGH + D::GHS + lane] = lg[0][2]; st[D::gGH + 2 * D::GHS + lane] = lg[0][3]; }
+      if (k < N) {
+        form_Pb(st);
+        sync();
+        CMPC_TICK(13);
+        gl_dot[0] = list_dot(0, &L(D::oLAMN));
+        if (lane < NZ) { L(D::oH0 + lane) = list_dot(0, &L(D::oXN1)); L(D::oH1 + lane) = list_dot(0, &R(D::oPC1)); }
+        gt_phase<false>(L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
+      } else {
+        gl_dot[0] = 0.0;
+        for (int e = lane; e < D::NTRI; e += WS) L(D::oM + e) = 0.0;    // terminal node: no cost-to-go; the Hessian rows add to zero
+        sync();
+      }
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+    }
     stage_ineq(k, x0n2);
     CMPC_TICK(12);
     // barrier weights (W2 holds the activity flag on entry); on the very first sweep the slacks and
@@ -1434,17 +1708,18 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         L(D::oW0 + r) = 0.0; L(D::oW1 + r) = 0.0; L(D::oW2 + r) = 0.0; L(D::oZK + r) = 0.0;
       }
     }
-    if (k < N && lane < NXA) er.e_p = fmax(er.e_p, fabs(L(D::oBV + lane)));
+    if constexpr (!D::GT_FIRST) { if (k < N && lane < NXA) er.e_p = fmax(er.e_p, fabs(L(D::oBV + lane))); }
     if (k >= 1 && lane < NXA) { er.sum_mult += fabs(L(D::oLAMK + lane)); er.n_mult += 1; }
     sync();
     CMPC_TICK(25);
-    // Hessian rows first: the column lists of [B A] (18 registers per lane) are not live across them
-    CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-    build_H(k, reg, wz);
-    CMPC_TICK(1);
-    CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-    build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
-    const GArr st = stage(k);
+    if constexpr (!D::GT_FIRST) {
+      // Hessian rows first: the column lists of [B A] (18 registers per lane) are not live across them
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+      build_H(k, reg, wz);
+      CMPC_TICK(1);
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+      build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
+    }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int col = lane + WS * h;
@@ -1453,22 +1728,42 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       double jw[3];
       jgt3(k, col, jw);
       double r = ho + jw[0];
-      if (k < N) for (int n = 0; n < 6; ++n) r += lg[h][n] * L(D::oLAMN + lr[h][n]);
+      if constexpr (D::GT) {                   // (the list's part summed on its own: the single wave formed it before G'PG)
+        if constexpr (!D::GT_FIRST) gl_dot[h] = (k < N) ? list_dot(h, &L(D::oLAMN)) : 0.0;
+        r += gl_dot[h];
+      } else {
+        if (k < N) for (int n = 0; n < 6; ++n) r += lg[h][n] * L(D::oLAMN + lr[h][n]);
+      }
       if (col >= NU) r -= L(D::oLAMK + col - NU);
       const bool is_var = (col < NU) ? (k < N) : (k >= 1);
       if (is_var) er.e_d = fmax(er.e_d, fabs(r));
-      L(D::oH0 + col) = ho + jw[1] + mu * jw[2];   // gradient at the sweep's barrier value (see backward_vectors)
-      L(D::oH1 + col) = jw[2];
+      double h0 = ho + jw[1] + mu * jw[2];     // gradient at the sweep's barrier value (see backward_vectors)
+      double h1 = jw[2];
+      CMPC_OPAQUE_D(h0); CMPC_OPAQUE_D(h1);    // (rounded here: see list_dot)
+      if constexpr (D::GT_FIRST) {             // m = h + [B A]' (.) of the backward vectors: the list's part is waiting there
+        if (k < N) { L(D::oH0 + col) = h0 + L(D::oH0 + col); L(D::oH1 + col) = h1 + L(D::oH1 + col); }
+        else { L(D::oH0 + col) = h0; L(D::oH1 + col) = h1; }
+      } else {
+        L(D::oH0 + col) = h0; L(D::oH1 + col) = h1;
+      }
       st[D::gAL + col] = L(D::oAL + col);
     }
     CMPC_TICK(26);
+    if constexpr (!D::GT_FIRST) {
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const int c = lane + WS * h;
-      if (c < NZ) { st[D::gGH + c] = L(D::oGH + c); st[D::gGH + D::GHS + c] = L(D::oGH + NZ + c); st[D::gGH + 2 * D::GHS + c] = L(D::oGH + 2 * NZ + c); }
+      for (int h = 0; h < NH; ++h) {
+        const int c = lane + WS * h;
+        if (c < NZ) { st[D::gGH + c] = L(D::oGH + c); st[D::gGH + D::GHS + c] = L(D::oGH + NZ + c); st[D::gGH + 2 * D::GHS + c] = L(D::oGH + 2 * NZ + c); }
+      }
     }
     for (int r = lane; r < NI; r += WS) st[D::gG + r] = L(D::oGK + r);
     CMPC_TICK(0);
+    if constexpr (D::GT_FIRST) {
+      // the Hessian rows add themselves to [B A]' P [B A] (read-modify-write of the row's non-zero columns)
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+      build_H(k, reg, wz);
+      CMPC_TICK(1);
+    }
     sync();
   }
   CMPC_DEV bool riccati_stage(int k) {
@@ -1478,51 +1773,20 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       build_list(&L(D::oGH), (k < N) ? L(D::oSR + 17) : 0.0, (k < N) ? L(D::oSR + 18) : 0.0, L(D::oHDR + 20));
     }
     if (k < N) {
-      // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG  (PIPE: P b is the other wave's, pair_vectors)
-      if (!PIPE && lane < NXA) {
-        const double *bv = &L(D::oBV);
-        double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-        if constexpr (D::P_PACKED) {
-          // row `lane` of the packed triangle: columns <= lane contiguous in the row, the others down column `lane`
-          static_assert(!D::P_PACKED || NXA == 28, "three batches of ten");
-          double pr[30];
-          {
-            const int tl = tri(lane);
-#pragma unroll
-            for (int q0 = 0; q0 < 30; q0 += 10) {
-              cmpc_lds_word pa[10];
-              double v[10];
-#pragma unroll
-              for (int q = 0; q < 10; ++q) {
-                const int qq = (q0 + q < NXA) ? q0 + q : NXA - 1;          // (the last batch repeats column 27 twice)
-                pa[q] = cmpc_lds_word_at(&R(D::oP), (qq <= lane) ? tl + qq : tri(qq) + lane);
-              }
-              lds_read_gather10(v, pa);
-#pragma unroll
-              for (int q = 0; q < 10; ++q) pr[q0 + q] = v[q];
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < NXA; q += 4) {
-            b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
-          }
-        } else {
-        const double *pr = &R(D::oP + lane * D::PS);
-#pragma unroll
-        for (int q = 0; q < NXA; q += 4) {
-          b0 += pr[q] * bv[q]; b1 += pr[q + 1] * bv[q + 1]; b2 += pr[q + 2] * bv[q + 2]; b3 += pr[q + 3] * bv[q + 3];
-        }
-        }
-        const double a = (b0 + b1) + (b2 + b3);
-        L(D::oXN1 + lane) = R(D::oPC + lane) + a;       // v0 = p0_{k+1} + P_{k+1} b
-        st[D::gB + lane] = L(D::oBV + lane);
+      if constexpr (!D::GT_FIRST) {
+        // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG  (PIPE: P b is the other wave's, pair_vectors)
+        if constexpr (!PIPE) form_Pb(st);
+        sync();                            // (8-vertex solver: the T tile of add_GtPG is its own region)
+        CMPC_TICK(13);
+        CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+        if constexpr (D::GT) gt_phase<true>(L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
+        else add_GtPG(L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
+        CMPC_TICK(14);
       }
-      sync();                            // the T tile of add_GtPG aliases BV and the other stage vectors
-      CMPC_TICK(13);
       CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-      add_GtPG(L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
-      CMPC_TICK(14);
-      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+#ifdef CMPC_DEBUG_PREFACTOR                    // (diagnostic build, tools/slab_diff.py: stage 0's block as it stands before the factorisation)
+      if (k == 0) { store_factors(k); sync(); return true; }
+#endif
       if (!factor_stage(k)) return false;
       CMPC_TICK(8);
       if constexpr (!PIPE) backward_vectors(k);    // (PIPE: the vector recursion follows one step behind, on the other wave)
@@ -2162,6 +2426,9 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         if (reg > 1e20) { fail = true; break; }
       }
       if (fail) { st = CMPC_NUMERICAL; break; }
+#ifdef CMPC_DEBUG_FIRST_SWEEP                  // (diagnostic build, tools/slab_diff.py: leave the slab as the first matrix sweep wrote it)
+      if (it == 0) break;
+#endif
       double e_d = red_max(er.e_d), e_p = red_max(er.e_p), e_c = red_max(er.e_c), e_cmu = red_max(er.e_cmu);
       double sm = red_sum(er.sum_mult), nm = red_sum((double)er.n_mult);
       if constexpr (PIPE) {

@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__re
       }
 #pragma unroll
       for (int j = 0; j < ND; ++j) {
+        if (j % 6 == 0) asm volatile("" : "+v"(ln));       // (predicates of later pivots are not formed -- and held -- ahead of time)
         const double dj = bcast(ac[j], j);
         ok0 = ok0 && (dj > 0.0);
         dlc = (ln == j) ? dj : dlc;
@@ -270,11 +271,29 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__re
       // the factor by columns
       asm volatile("" : "+v"(ln));
       double y = rhs;
+      {
+        // the constant columns come back from the packed factor in LDS (row `ln`, contiguous: written once per instance),
+        // fifteen words at a time -- held in registers across the Newton loop they were 60 of the kernel's 256 and the
+        // reason for its spills (round 4: 116 bytes of scratch per lane)
+        const double *lrow = &L[oL + tri((ln < NK) ? ln : 0)];
 #pragma unroll
-      for (int j = 0; j < NK; ++j) {
+        for (int j0 = 0; j0 < ND; j0 += 15) {
+          double lc[15];
+#pragma unroll
+          for (int q = 0; q < 15; ++q) lc[q] = lrow[j0 + q];         // (words at or right of the diagonal: never used)
+#pragma unroll
+          for (int q = 0; q < 15; ++q) {
+            const int j = j0 + q;
+            const double yj = bcast(y, j);
+            if (ln > j) y -= lc[q] * yj;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int j = ND; j < NK; ++j) {
         const double yj = bcast(y, j);
-        const double lj = (j < ND) ? ac[j] : w[(j < ND) ? 0 : j - ND];
-        if (ln > j) y -= lj * yj;
+        if (ln > j) y -= w[j - ND] * yj;
       }
       y *= pivot_rcp(dl);
       if (ln < NK) {

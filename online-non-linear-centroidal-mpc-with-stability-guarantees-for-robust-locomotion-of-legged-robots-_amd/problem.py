@@ -49,6 +49,8 @@ class ProblemSpec:
     tol: float = 1e-8             # KKT tolerance of the batched solver
     acc_tol: float = 1e-4         # acceptable level (status 3); the reference's IPOPT runs tol = 1e-3 (:128)
     max_iter: int = 100
+    kernel: int = 0               # CMPC_KERNEL_* (include/cmpc.h): 0 auto, 1 one wavefront per instance, 2 the pipelined pair
+    reserved: int = 0
 
     @property
     def nu(self):
@@ -149,7 +151,8 @@ class CSpec(ctypes.Structure):
                 ("cz_max", ctypes.c_double), ("box", ctypes.c_double * 3),
                 ("foot_length", ctypes.c_double), ("foot_width", ctypes.c_double),
                 ("prox", ctypes.c_double), ("relax", ctypes.c_double),
-                ("tol", ctypes.c_double), ("acc_tol", ctypes.c_double)]
+                ("tol", ctypes.c_double), ("acc_tol", ctypes.c_double),
+                ("kernel", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 def to_cspec(spec):

@@ -112,6 +112,10 @@ class BatchedCentroidalMPC:
         """An empty solver state for B instances (barrier word 0 = "no state": the first tick starts cold)."""
         return torch.zeros((B, self.spec.nstate), dtype=torch.float64, device=self.device)
 
+    def last_kernel_name(self):
+        """Name of the solver kernel the last solve launched, as the library reports it (cmpc_last_kernel_name)."""
+        return self._lib.cmpc_last_kernel_name(self._h).decode()
+
     def last_kernel_ms(self):
         """Duration of the last solve's kernel (HIP events on the launch stream); synchronises."""
         ms = ctypes.c_float()

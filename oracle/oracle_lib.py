@@ -23,7 +23,8 @@ class CSpec(ctypes.Structure):
                 ("cz_max", ctypes.c_double), ("box", ctypes.c_double * 3),
                 ("foot_length", ctypes.c_double), ("foot_width", ctypes.c_double),
                 ("prox", ctypes.c_double), ("relax", ctypes.c_double),
-                ("tol", ctypes.c_double), ("acc_tol", ctypes.c_double)]
+                ("tol", ctypes.c_double), ("acc_tol", ctypes.c_double),
+                ("kernel", ctypes.c_int32), ("reserved", ctypes.c_int32)]   # (kernel choice of the HIP library: unused here)
 
 
 def build(force=False):

@@ -122,7 +122,7 @@ extern "C" int cmpc_emu_solve_batch_state(const cmpc_spec *sp, int32_t B, const 
                     : (nw8 == 2)  ? cmpc::Dims<8, 2>::scratch_doubles(sp->N) : cmpc::Dims<8>::scratch_doubles(sp->N);
   // CMPC_EMU_PAIR=1 runs the 4-vertex solver as the pipelined pair of waves (two LDS images + the exchange words)
   const bool pair = sp->nv == 4 && getenv("CMPC_EMU_PAIR") && atoi(getenv("CMPC_EMU_PAIR")) == 1;
-  const size_t nl = pair ? 2 * cmpc::Dims<4>::LDS_DOUBLES : (sp->nv == 4) ? cmpc::Dims<4>::LDS_DOUBLES
+  const size_t nl = pair ? 2 * cmpc::Dims<4, 1, true>::LDS_DOUBLES : (sp->nv == 4) ? cmpc::Dims<4>::LDS_DOUBLES
                     : (nw8 == 2)  ? cmpc::Dims<8, 2>::LDS_DOUBLES : cmpc::Dims<8>::LDS_DOUBLES;
   const double fill = getenv("CMPC_EMU_FILL") ? atof(getenv("CMPC_EMU_FILL")) : 0.0;
   std::vector<double> scratch(nd, fill), lds(nl, fill);

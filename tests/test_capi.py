@@ -45,7 +45,8 @@ def test_default_spec_and_struct_layout(lib):
             assert list(a) == list(b)
         else:
             assert a == b, name
-    assert ctypes.sizeof(CSpec) == 4 * 4 + 20 * 8            # 4 int32 + 20 doubles, no padding surprises
+    assert ctypes.sizeof(CSpec) == 4 * 4 + 20 * 8 + 2 * 4    # 4 int32 + 20 doubles + kernel, reserved: no padding surprises
+    assert c.kernel == 0 and c.reserved == 0                 # CMPC_KERNEL_AUTO
     assert lib.cmpc_version().decode().startswith("cmpc_amd")
 
 
@@ -56,6 +57,10 @@ def test_workspace_bytes_and_argument_checks(lib):
     assert lib.cmpc_workspace_bytes(ctypes.byref(c), 1 << 21) - big == 8 * (1 << 20)   # only the queue order (position + bucket key per instance) grows
     bad = to_cspec(ProblemSpec(N=20, nv=4)); bad.nv = 5
     assert lib.cmpc_workspace_bytes(ctypes.byref(bad), 16) == 0
+    for spec_, ok in ((ProblemSpec(N=20, nv=4, kernel=2), True), (ProblemSpec(N=20, nv=4, kernel=3), False),
+                      (ProblemSpec(N=20, nv=8, kernel=2), False), (ProblemSpec(N=20, nv=8, kernel=1), True)):
+        assert (lib.cmpc_workspace_bytes(ctypes.byref(to_cspec(spec_)), 16) > 0) == ok      # the pair kernel exists for nv = 4 only
+    assert lib.cmpc_last_kernel_name(None) == b""
     h = ctypes.c_void_p()
     assert lib.cmpc_create(ctypes.byref(bad), 0, ctypes.byref(h)) != 0
     assert b"invalid spec" in lib.cmpc_last_error(None)
@@ -103,10 +108,8 @@ def test_four_vertex_kernel_has_no_spill_code_in_its_stage_loops(tmp_path):
     """The hot kernel (cmpc_solve_kernel<4>) must not spill vector registers where it matters: a scratch reload is an
     exposed memory round trip for a wave that has nothing else to run (round-2 review: Scratch_Size 96 B/lane, 30 VGPR
     spills, some of them inside the stage loops).  Read from the cross-compiled ISA and its code-object metadata, no GPU
-    needed: at most 16 bytes of scratch per lane, and every scratch instruction sits OUTSIDE the stage loops (loop depth
-    <= 3 = instance loop, attempt loop, iteration loop: executed once per iteration at most, against ~21 stages x
-    ~7000 instructions per iteration).  Round 3 had none at all; round 4's branch-free state-update rows (+1.8 %) cost
-    three registers kept across the vector sweep, saved and restored once per iteration."""
+    needed: NO scratch and no spilled vector register at all (what rounds 3 and 4 shipped; a build that needs some is a
+    regression to look at, not a level to widen)."""
     import re
     import subprocess
     src = os.path.join(_b.PKG, "csrc", "cmpc_hip.hip")
@@ -121,8 +124,8 @@ def test_four_vertex_kernel_has_no_spill_code_in_its_stage_loops(tmp_path):
     scratch = int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", meta).group(1))
     spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1))
     lds = int(re.search(r"\.group_segment_fixed_size:\s*(\d+)", meta).group(1))
-    assert scratch <= 16 and spills <= 4, (scratch, spills)
-    assert 6 * ((lds + 1279) // 1280 * 1280) <= 160 * 1024      # six workgroups per CU (LDS comes in 1280-byte granules)
+    assert scratch == 0 and spills == 0, (scratch, spills)
+    assert 6 * ((lds + 1279) // 1280 * 1280) <= 160 * 1024      # at least six workgroups per CU (LDS comes in 1280-byte granules)
     # loop depth of every basic block that holds a scratch instruction (the assembler comments carry it)
     body = isa[isa.index("cmpc_solve_kernelILi4ELi1EEEvN4cmpc5KArgsEPiPKi:"):]
     body = body[:body.index("s_endpgm")]

@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, B, N, tmp):
+def _worker(rank, world, port, B, N, tmp, deal=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
@@ -42,7 +42,7 @@ def _worker(rank, world, port, B, N, tmp):
         out, st, it, kkt = ol.solve_batch(cs, shard.numpy(), nthreads=1)
         return torch.from_numpy(out), torch.from_numpy(st), torch.from_numpy(it), torch.from_numpy(kkt)
 
-    fb, st, it = cdist.solve_sharded(solve_fn, torch.from_numpy(rec), spec.N, spec.nu)
+    fb, st, it = cdist.solve_sharded(solve_fn, torch.from_numpy(rec), spec.N, spec.nu, deal_spec=spec if deal else None)
     np.save(os.path.join(tmp, f"fb{rank}.npy"), fb.numpy())
     np.save(os.path.join(tmp, f"st{rank}.npy"), st.numpy())
     dist.barrier()
@@ -64,6 +64,40 @@ def test_two_rank_gloo_shard_and_gather(tmp_path, oracle, B):
         assert got.shape == (B, 20 + spec.nu)
         assert np.array_equal(got, want)                     # every rank holds the full, ordered result
         assert np.array_equal(np.load(tmp_path / f"st{r}.npy"), st)
+
+
+def test_shard_order_deals_every_instance_once_and_by_predicted_cost():
+    from cmpc_amd import workloads as wl, queue_order as qo
+    spec, rec = wl.make_workload("randomized", B=1001, N=20)
+    for world in (1, 2, 3, 8):
+        order = cdist.shard_order(rec, spec, world)
+        assert sorted(order.tolist()) == list(range(1001))
+        sizes = [len(cdist.dealt_rows(order, world, r)) for r in range(world)]
+        assert sizes == [hi - lo for lo, hi in (cdist.shard_bounds(1001, world, r) for r in range(world))]
+        if world > 1:
+            key = qo.bucket_of(qo.predicted_iterations(rec, spec))
+            assert (np.diff(key[order]) <= 0).all()                     # by decreasing predicted cost, ...
+            pred = qo.predicted_iterations(rec, spec)
+            loads = [pred[cdist.dealt_rows(order, world, r)].sum() for r in range(world)]
+            cont = [pred[lo:hi].sum() for lo, hi in (cdist.shard_bounds(1001, world, r) for r in range(world))]
+            assert max(loads) - min(loads) <= max(cont) - min(cont) + 1e-9   # ... which balances the predicted load
+    assert cdist.shard_order(rec[:0], spec, 4).shape == (0,)
+
+
+@pytest.mark.parametrize("world,B", [(2, 7), (3, 10), (3, 3)])
+def test_dealt_shards_gather_back_to_input_order(tmp_path, oracle, world, B):
+    """The deal by predicted cost over world-size 2 and 3 with ragged batches: the gathered tensor is bit for
+    bit what the contiguous path returns, on every rank."""
+    N = 4
+    for deal in (False, True):
+        d = tmp_path / ("deal" if deal else "cont")
+        d.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), B, N, str(d), deal), nprocs=world, join=True)
+    for r in range(world):
+        for name in ("fb", "st"):
+            a, b = np.load(tmp_path / "cont" / f"{name}{r}.npy"), np.load(tmp_path / "deal" / f"{name}{r}.npy")
+            assert np.array_equal(a, b), (name, r)
+    assert np.array_equal(np.load(tmp_path / "deal" / "fb0.npy"), np.load(tmp_path / "deal" / f"fb{world - 1}.npy"))
 
 
 def test_gather_is_identity_without_process_group():

@@ -1,6 +1,7 @@
 """Parity tests proper: the HIP solver, called through the C ABI, against the C oracle on the same
 seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full sizes -- through
 size-independent properties.  Tolerance (north star): 1e-4 rel-inf; what is asserted is tighter."""
+import dataclasses
 import glob
 import os
 
@@ -27,58 +28,95 @@ def gpu():
     return BatchedCentroidalMPC
 
 
-def _solve(gpu, spec, rec, warm=None):
+def _solve(gpu, spec, rec, warm=None, kernel=None):
+    """kernel: None = the library's own choice; "single" / "pair" = cmpc_spec.kernel fixed when the handle is created."""
+    if kernel is not None:
+        spec = dataclasses.replace(spec, kernel=KERNELS[kernel])
     s = gpu(spec, device="cuda:0")
     w = None if warm is None else torch.from_numpy(np.ascontiguousarray(warm)).to("cuda:0")
     out, st, it, kkt = s.solve(torch.from_numpy(np.ascontiguousarray(rec)).to("cuda:0"), warm=w)
     torch.cuda.synchronize()
+    if kernel is not None and rec.shape[0] > 0:
+        assert s.last_kernel_name() == KERNEL_NAMES[(kernel, spec.nv)], s.last_kernel_name()
     return out.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), kkt.cpu().numpy()
 
 
-def _explain_outliers(oracle, cs, spec, rec, got, ref, idx, uprox=None, obj_tol=1e-7, kkt=None, kkt_ref=None):
-    """Every pair of solutions further apart than the north-star tolerance must be the SAME optimum seen from
-    two points of a flat valley (curvature = the 1e-4 proximal weight against a 1e-8 KKT tolerance): equal
-    objective value, dynamics satisfied, inequalities satisfied.  Nothing else may pass.
+# ---------------------------------------------------------------------------------------------------------------------
+# LEVELS.  Written once, from the problem's own constants, before the round's first GPU run of this file; not to be moved
+# after a red run (a level that has to move is recorded with before / after and the run that forced it in DESIGN.md 2).
+#
+#   TOL = 1e-8      scaled KKT tolerance of a "converged" point (status 0; after the polish step at most 100 TOL)
+#   ACC = 1e-4      acceptable level (status 3): such a point reports its own final scaled KKT error kappa <= ACC
+#   RHO = 1e-4      proximal weight = the curvature of the objective along the directions the NLP leaves flat
+#
+# Two points that both satisfy the KKT conditions to kappa agree
+#   * in objective to first order in kappa (through the multipliers, scale <= 10): |dJ| / J <= 10 kappa,
+#   * in their constraint residuals to kappa,
+#   * along a flat direction only to (multiplier scale) x kappa / RHO.
+# kappa is what the solvers report per instance, capped at KAPPA_CAP = 1e-5: the largest final error of a usable point on
+# the full bench batch is 6e-6 (BENCH_r04, `kkt.max`); nothing is granted beyond what the data shows.
+# A pair of status-0 points gets NO kappa allowance: objective to OBJ_TIGHT, residuals to RES_TIGHT, displacement within
+# 100 TOL / RHO = 1e-2 at the very most (measured max over 16 384 tight pairs: 2e-4).
+TOL, ACC, RHO = 1e-8, 1e-4, 1e-4
+KAPPA_CAP = 1e-5
+OBJ_TIGHT, RES_TIGHT = 1e-7, 1e-7
+FLAT_TIGHT = 100 * TOL / RHO                     # 1e-2
 
-    Levels, stated from the problem: a point that met the tolerance agrees in objective to `obj_tol` and satisfies its
-    constraints to 1e-7.  A point returned at the ACCEPTABLE level carries its own final scaled KKT error kappa
-    (<= acc_tol, reported per instance): its constraint residuals are bounded by kappa, and the objective is first-order
-    sensitive to them through the multipliers, so for such a pair the objective may differ by 10 * kappa relative and
-    the residuals may reach kappa."""
+
+def pair_allowance(st_a, st_b, kkt_a, kkt_b):
+    """(objective, residual, displacement) a pair of usable answers may differ by, from the table above."""
+    if st_a == 0 and st_b == 0:
+        return OBJ_TIGHT, RES_TIGHT, FLAT_TIGHT
+    kap = min(KAPPA_CAP, max(float(kkt_a) if st_a == 3 else 0.0, float(kkt_b) if st_b == 3 else 0.0))
+    return max(OBJ_TIGHT, 10 * kap), max(RES_TIGHT, kap), max(FLAT_TIGHT, 10 * kap / RHO)
+
+
+def _explain_outliers(oracle, cs, spec, rec, got, ref, idx, st, st_ref, kkt, kkt_ref, uprox=None, obj_tol=OBJ_TIGHT):
+    """Every pair of solutions further apart than the north-star tolerance must be the SAME optimum seen from two points
+    of a flat valley: equal objective value, dynamics satisfied, inequalities satisfied, displacement within what the
+    curvature RHO allows at the pair's KKT error (`pair_allowance`).  Nothing else may pass."""
     nU = 20 * (spec.N + 1)
     for i in idx:
         up = None if uprox is None else uprox[i, nU:]
-        kap = 0.0 if kkt is None else max(float(kkt[i]), float(kkt_ref[i]) if kkt_ref is not None else 0.0)
+        a_obj, a_res, a_flat = pair_allowance(st[i], st_ref[i], kkt[i], kkt_ref[i])
         f_g, def_g, ineq_g, act_g = oracle.evaluate(cs, rec[i], got[i], uprox=up)
         f_r, def_r, ineq_r, act_r = oracle.evaluate(cs, rec[i], ref[i], uprox=up)
-        assert abs(f_g - f_r) <= max(obj_tol, 10 * kap) * max(1.0, abs(f_r)), (i, f_g, f_r, kap)
-        assert np.abs(def_g).max() < max(1e-7, kap), (i, np.abs(def_g).max(), kap)
-        assert ineq_g[act_g == 1].max() <= max(1e-7, kap), (i, ineq_g[act_g == 1].max(), kap)
+        assert abs(f_g - f_r) <= max(obj_tol, a_obj) * max(1.0, abs(f_r)), (i, f_g, f_r, st[i], st_ref[i], kkt[i], kkt_ref[i])
+        assert np.abs(def_g).max() < a_res, (i, np.abs(def_g).max(), a_res)
+        assert ineq_g[act_g == 1].max() <= a_res, (i, ineq_g[act_g == 1].max(), a_res)
+        assert rel_inf(got[i], ref[i])[0] <= a_flat, (i, rel_inf(got[i], ref[i])[0], a_flat)
 
 
-# (median over usable pairs, median over tight pairs, q90 over tight pairs, share of pairs beyond 1e-4, objective
-# agreement demanded of those).  Measured levels: tools/parity_report.py, profiles/r02_parity_report.txt.
+# Population levels per problem class: (median over usable pairs, median over tight pairs, q90 over tight pairs, share of
+# pairs beyond 1e-4, objective agreement demanded of those).  Measured: tools/parity_report.py, profiles/r04m_parity_report.txt.
 #   nominal   delta = 0.01 s, N <= 20 (the north-star case): rounding level, outliers = flat valleys
 #   long      N = 40: rounding errors of 40 stages add up; same rule for the outliers
 #   rate10    mpc_rate = 10 (delta = 0.1 s, horizons of 1-2 s over several steps, no force-rate cost): a fifth of
-#             the instances stop at the acceptable level (KKT ~1e-6) in one solver or the other, where the flat
-#             directions are resolved to ~1e-2 only; one pair in ~60 sits in two different local minima
+#             the instances stop at the acceptable level (KKT ~1e-6) in one solver or the other (DESIGN.md 2: the exact
+#             Hessian is indefinite at the stationary point itself); one pair in ~60 sits in two different local minima
 #             (objectives 8e-6 apart, both converged) -- the NLP is not convex
-LEVELS = {"nominal": (1e-9, 1e-9, 1e-6, 0.06, 1e-7), "long": (1e-6, 1e-9, 1e-4, 0.10, 1e-7),
-          "rate10": (1e-4, 1e-6, 1e-3, 0.40, 2e-5)}
+LEVELS = {"nominal": (1e-9, 1e-9, 1e-6, 0.06, OBJ_TIGHT), "long": (1e-6, 1e-9, 1e-4, 0.10, OBJ_TIGHT),
+          "rate10": (1e-4, 1e-6, 1e-3, 0.40, 2e-5)}          # (share beyond 1e-4 measured: 0.24 at N = 10, 0.33 at N = 20)
+
+# Both solver kernels of the 4-vertex solver are held to every oracle-parity test: the one-wavefront kernel (what
+# `bench.py` times at B = 8192) and the pipelined pair (what small batches run), chosen through cmpc_spec.kernel.
+KERNELS = {"single": 1, "pair": 2}
+KERNEL_NAMES = {("single", 4): "cmpc_solve_kernel<4, 1>", ("pair", 4): "cmpc_solve_pair_kernel<4, 2>",
+                ("single", 8): "cmpc_solve_kernel<8, 2>"}
+CASES = [("perturbed", 256, 20, 1), ("payload", 512, 20, 1), ("randomized", 512, 20, 1), ("perturbed", 128, 10, 1),
+         ("perturbed", 64, 3, 1), ("perturbed", 32, 40, 1), ("long_horizon", 64, 10, 1), ("long_horizon", 48, 40, 1),
+         ("perturbed", 128, 10, 10), ("perturbed", 64, 20, 10)]
+CASES_BY_KERNEL = [c + (k,) for c in CASES for k in (("single",) if c[0] == "long_horizon" else ("single", "pair"))]
 
 
-@pytest.mark.parametrize("name,B,N,rate", [("perturbed", 256, 20, 1), ("payload", 512, 20, 1), ("randomized", 512, 20, 1),
-                                             ("perturbed", 128, 10, 1), ("perturbed", 64, 3, 1), ("perturbed", 32, 40, 1),
-                                             ("long_horizon", 64, 10, 1), ("long_horizon", 48, 40, 1),
-                                             ("perturbed", 128, 10, 10), ("perturbed", 64, 20, 10)])
-def test_parity_with_oracle(gpu, oracle, name, B, N, rate):
+@pytest.mark.parametrize("name,B,N,rate,kernel", CASES_BY_KERNEL)
+def test_parity_with_oracle(gpu, oracle, name, B, N, rate, kernel):
     spec, rec = wl.make_workload(name, B=B, N=N, rate=rate)
     if N > 20:
         spec.max_iter = 150                                   # long horizons take more iterations
     med_all, med_tight, q90_tight, share, obj_tol = LEVELS["rate10" if rate == 10 else "long" if N > 20 else "nominal"]
     cs = oracle_spec(oracle, spec)
-    got, st, it, kkt = _solve(gpu, spec, rec)
+    got, st, it, kkt = _solve(gpu, spec, rec, kernel=kernel)
     ref, st_ref, it_ref, kkt_ref = oracle.solve_batch(cs, rec)
     ok_g, ok_r = np.isin(st, (0, 3)), np.isin(st_ref, (0, 3))
     # same verdict (usable: converged / acceptable, or not) on (nearly) every instance; whether a slowly
@@ -90,27 +128,55 @@ def test_parity_with_oracle(gpu, oracle, name, B, N, rate):
     tight = (st == 0) & (st_ref == 0)
     err_t = rel_inf(got[tight], ref[tight])
     assert np.median(err) < med_all and np.median(err_t) < med_tight and np.quantile(err_t, 0.9) < q90_tight
+    assert err_t.max() <= FLAT_TIGHT                          # hard ceiling on every pair of converged points
     # north star: within 1e-4 rel-inf.  Pairs beyond it are allowed only if they are explained (same optimum,
     # flat valley) -- checked for every one of them -- and they are few.
     out = np.where(both)[0][err >= REL_TOL]
     assert len(out) <= share * both.sum(), (len(out), int(both.sum()))
-    _explain_outliers(oracle, cs, spec, rec, got, ref, out, obj_tol=obj_tol, kkt=kkt, kkt_ref=kkt_ref)
+    _explain_outliers(oracle, cs, spec, rec, got, ref, out, st, st_ref, kkt, kkt_ref, obj_tol=obj_tol)
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "solver_kat_*.npz"))),
-                         ids=lambda p: os.path.basename(p))
-def test_golden_vectors(gpu, path):
+def test_parity_sample_from_a_launch_beyond_the_pair_threshold(gpu, oracle):
+    """The library's own choice at the bench's batch size (B = 8192 > 20 instances per CU) is the one-wavefront kernel with
+    its ticket queue running well past the resident grid: a sample of that launch -- early and late queue positions --
+    against the oracle, same levels as above."""
+    spec, rec = wl.make_workload("randomized", B=8192, N=20)
+    s = gpu(spec, device="cuda:0")
+    out, st, it, kkt = s.solve(torch.from_numpy(rec).to("cuda:0"))
+    torch.cuda.synchronize()
+    assert s.last_kernel_name() == "cmpc_solve_kernel<4, 1>"
+    got, st, kkt = out.cpu().numpy(), st.cpu().numpy(), kkt.cpu().numpy()
+    idx = np.concatenate([np.arange(0, 8192, 32), np.arange(8000, 8192)])
+    cs = oracle_spec(oracle, spec)
+    ref, st_ref, _, kkt_ref = oracle.solve_batch(cs, rec[idx])
+    ok = np.isin(st[idx], (0, 3)) & np.isin(st_ref, (0, 3))
+    assert (np.isin(st[idx], (0, 3)) != np.isin(st_ref, (0, 3))).sum() <= 2 and ok.mean() > 0.9
+    err = rel_inf(got[idx][ok], ref[ok])
+    med_all, _, _, share, obj_tol = LEVELS["nominal"]
+    assert np.median(err) < med_all
+    far = np.where(ok)[0][err >= REL_TOL]
+    assert len(far) <= share * ok.sum()
+    _explain_outliers(oracle, cs, spec, rec[idx], got[idx], ref, far, st[idx], st_ref, kkt[idx], kkt_ref, obj_tol=obj_tol)
+
+
+def _kernels_of(path):
+    return ("single", "pair") if int(np.load(path)["nv"]) == 4 else ("single",)
+
+
+@pytest.mark.parametrize("path,kernel", [(p, k) for p in sorted(glob.glob(os.path.join(GOLD, "solver_kat_*.npz"))) for k in _kernels_of(p)],
+                         ids=lambda v: os.path.basename(v) if v.endswith(".npz") else v)
+def test_golden_vectors(gpu, path, kernel):
     kat = np.load(path)
     spec = ProblemSpec(N=int(kat["N"]), nv=int(kat["nv"]), k1=float(kat["k1"]), k2=float(kat["k2"]),
                        tol=1e-10, max_iter=300)
-    got, st, it, kkt = _solve(gpu, spec, kat["records"])
+    got, st, it, kkt = _solve(gpu, spec, kat["records"], kernel=kernel)
     assert np.isin(st, (0, 3)).all() and kkt.max() <= 1e-8
     assert rel_inf(got, kat["solutions"]).max() < 1e-5
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "independent_pin_*.npz"))),
-                         ids=lambda p: os.path.basename(p)[16:-4])
-def test_independent_pins(gpu, oracle, path):
+@pytest.mark.parametrize("path,kernel", [(p, k) for p in sorted(glob.glob(os.path.join(GOLD, "independent_pin_*.npz"))) for k in _kernels_of(p)],
+                         ids=lambda v: os.path.basename(v)[16:-4] if v.endswith(".npz") else v)
+def test_independent_pins(gpu, oracle, path, kernel):
     """The HIP solver against solutions computed without the C oracle (dense interior point on the literal torch
     restatement, scipy trust-constr): tests/test_independent_pins.py, tests/golden/make_independent_pins.py."""
     from test_independent_pins import check_against_pin
@@ -119,43 +185,46 @@ def test_independent_pins(gpu, oracle, path):
     # 1e-8, not at the default acceptable level 1e-4, which determines the flat directions to 1e-4 / 1e-4 = 1 only)
     spec = ProblemSpec(N=int(pin["N"]), nv=int(pin["nv"]), k1=float(pin["k1"]), k2=float(pin["k2"]), tol=1e-9, max_iter=200,
                        acc_tol=1e-8)
-    got, st, it, kkt = _solve(gpu, spec, pin["record"][None, :])
+    got, st, it, kkt = _solve(gpu, spec, pin["record"][None, :], kernel=kernel)
     # (status 0: the tolerance was met, the polish step that follows may leave up to 100 * tol; status 3: within acc_tol)
     assert (st[0] == 0 and kkt[0] < 1e-7) or (st[0] == 3 and kkt[0] <= 1e-8), (st, kkt)
     cs = oracle_spec(oracle, spec)
     check_against_pin(pin, got[0], lambda w: oracle.evaluate(cs, pin["record"], w), kkt=float(kkt[0]))
 
 
-def test_edge_cases_empty_single_and_ragged_batches(gpu, oracle):
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_edge_cases_empty_single_and_ragged_batches(gpu, oracle, kernel):
     spec, rec = wl.make_workload("perturbed", B=67, N=10, scale=0.5)
     ref, st_ref, _, kkt_ref = oracle.solve_batch(oracle_spec(oracle, spec), rec)
-    got0 = _solve(gpu, spec, rec[:0])
+    got0 = _solve(gpu, spec, rec[:0], kernel=kernel)
     assert got0[0].shape == (0, spec.nsol) and got0[1].shape == (0,)
     cs = oracle_spec(oracle, spec)
     for B in (1, 2, 63, 65, 67):                             # around the wavefront width
-        got, st, _, kkt = _solve(gpu, spec, rec[:B])
+        got, st, _, kkt = _solve(gpu, spec, rec[:B], kernel=kernel)
         ok = np.isin(st, (0, 3)) & np.isin(st_ref[:B], (0, 3))
         err = rel_inf(got[ok], ref[:B][ok])
         # all but the occasional flat-direction instance (curvature = the 1e-4 proximal weight against a KKT tolerance of
         # 1e-8: a displacement of 1e-4 is within the tolerance) agree to rounding level; a pair further apart than the
-        # north-star tolerance must be the same optimum -- equal objective, feasible -- and there may be one in a batch
+        # north-star tolerance must be the same optimum -- equal objective, feasible, within the displacement its KKT
+        # error allows (`pair_allowance`; for two converged points 1e-2 at the very most) -- and there may be one in a batch
         assert ok.mean() > 0.9 and np.median(err) < 1e-9
         far = np.where(ok)[0][err >= REL_TOL]
         assert len(far) <= max(1, 0.03 * B)
-        _explain_outliers(oracle, cs, spec, rec[:B], got, ref[:B], far, kkt=kkt, kkt_ref=kkt_ref[:B])
+        _explain_outliers(oracle, cs, spec, rec[:B], got, ref[:B], far, st, st_ref[:B], kkt, kkt_ref[:B])
 
 
-def test_batch_composition_does_not_change_results(gpu):
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_batch_composition_does_not_change_results(gpu, kernel):
     """Instances are independent: results are bitwise identical whatever else is in the batch, in
     whatever order, on every run (ticket order and slab reuse must not leak between instances)."""
-    spec, rec = wl.make_workload("randomized", B=3000, N=20)  # > resident grid: slabs are reused
-    a, st_a, it_a, _ = _solve(gpu, spec, rec)
-    b, st_b, it_b, _ = _solve(gpu, spec, rec)
+    spec, rec = wl.make_workload("randomized", B=3000, N=20)  # > resident grid of either kernel: slabs are reused
+    a, st_a, it_a, _ = _solve(gpu, spec, rec, kernel=kernel)
+    b, st_b, it_b, _ = _solve(gpu, spec, rec, kernel=kernel)
     assert np.array_equal(a, b) and np.array_equal(it_a, it_b)
     perm = np.random.default_rng(0).permutation(rec.shape[0])
-    c, st_c, it_c, _ = _solve(gpu, spec, rec[perm])
+    c, st_c, it_c, _ = _solve(gpu, spec, rec[perm], kernel=kernel)
     assert np.array_equal(c, a[perm]) and np.array_equal(st_c, st_a[perm])
-    d, _, _, _ = _solve(gpu, spec, rec[100:164])
+    d, _, _, _ = _solve(gpu, spec, rec[100:164], kernel=kernel)
     assert np.array_equal(d, a[100:164])
 
 
@@ -209,16 +278,17 @@ def test_eight_vertex_two_wave_kernel_edge_cases(gpu, oracle):
             assert abs(f_g - f_r) <= 1e-6 * max(1.0, abs(f_r)) and np.abs(d_g).max() < 1e-7
 
 
-def test_two_handles_on_two_streams_overlap_without_interference(gpu):
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_two_handles_on_two_streams_overlap_without_interference(gpu, kernel):
     """bench.py alternates consecutive batches over two solver handles on two HIP streams (the straggler
     tail of one launch overlaps the next).  Handles share nothing: the overlapped results are bitwise the
     serial ones."""
     spec, rec_a = wl.make_workload("randomized", B=2600, N=20)   # > resident grid, so the launches really overlap
     rec_b = rec_a[::-1].copy()
-    ref_a, st_a, _, _ = _solve(gpu, spec, rec_a)
-    ref_b, st_b, _, _ = _solve(gpu, spec, rec_b)
+    ref_a, st_a, _, _ = _solve(gpu, spec, rec_a, kernel=kernel)
+    ref_b, st_b, _, _ = _solve(gpu, spec, rec_b, kernel=kernel)
     d_a, d_b = (torch.from_numpy(r).to("cuda:0") for r in (rec_a, rec_b))
-    solvers = [gpu(spec, device="cuda:0") for _ in range(2)]
+    solvers = [gpu(dataclasses.replace(spec, kernel=KERNELS[kernel]), device="cuda:0") for _ in range(2)]
     streams = [torch.cuda.Stream() for _ in range(2)]
     torch.cuda.synchronize()
     outs = []
@@ -230,12 +300,13 @@ def test_two_handles_on_two_streams_overlap_without_interference(gpu):
     assert np.array_equal(outs[1][0].cpu().numpy(), ref_b) and np.array_equal(outs[1][1].cpu().numpy(), st_b)
 
 
-def test_warm_start_parity_and_speedup(gpu, oracle):
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_warm_start_parity_and_speedup(gpu, oracle, kernel):
     spec, rec = wl.make_workload("perturbed", B=64, N=20, scale=0.5)
     cs = oracle_spec(oracle, spec)
     cold, st0, it0, _ = oracle.solve_batch(cs, rec)
-    got, st, it, _ = _solve(gpu, spec, rec, warm=cold)
-    ref, st_ref, it_ref, _ = oracle.solve_batch(cs, rec, warm=cold)
+    got, st, it, kkt = _solve(gpu, spec, rec, warm=cold, kernel=kernel)
+    ref, st_ref, it_ref, kkt_ref = oracle.solve_batch(cs, rec, warm=cold)
     both = np.isin(st, (0, 3)) & np.isin(st_ref, (0, 3)) & np.isin(st0, (0, 3))
     assert both.mean() > 0.9
     # re-centred proximal term: curvature along the flat directions is the 1e-4 proximal weight, so with
@@ -244,7 +315,7 @@ def test_warm_start_parity_and_speedup(gpu, oracle):
     # objective value and dynamics defect (same optimum, different point of the flat valley).
     err = rel_inf(got[both], ref[both])
     assert np.median(err) < 1e-9 and np.quantile(err, 0.9) < REL_TOL
-    _explain_outliers(oracle, cs, spec, rec, got, ref, np.where(both)[0], uprox=cold)
+    _explain_outliers(oracle, cs, spec, rec, got, ref, np.where(both)[0], st, st_ref, kkt, kkt_ref, uprox=cold)
 
 
 def test_full_size_properties_domain_randomised(gpu):
@@ -410,20 +481,20 @@ def test_batched_closed_loop_rollout(gpu, scene):
     assert int(ro.t[0].item()) == t0 + ticks
 
 
-def test_pair_kernel_is_bitwise_the_single_wave_kernel(gpu, monkeypatch):
+def test_pair_kernel_is_bitwise_the_single_wave_kernel(gpu):
     """Small batches run two waves per instance (cmpc_solve_pair_kernel: evaluation of stage k - 1 beside the Riccati step of
     stage k).  Same arithmetic, same order: everything the call returns must be bit for bit what the one-wave kernel
     returns -- B = 1, a batch larger than the pair kernel's resident grid (several instances through one workgroup),
     cold and resumed from the solver state, the payload gains, the horizon limits of the build."""
     def both(spec, rec, warm=None, state=None):
         res = []
-        for pair in ("0", "1"):
-            monkeypatch.setenv("CMPC_PAIR", pair)              # developer knob read by cmpc_create: never / always
-            s = gpu(spec, device="cuda:0")
+        for kern in ("single", "pair"):                        # cmpc_spec.kernel, fixed when the handle is created
+            s = gpu(dataclasses.replace(spec, kernel=KERNELS[kern]), device="cuda:0")
             d = torch.from_numpy(np.ascontiguousarray(rec)).cuda()
             so = s.new_state(rec.shape[0])
             out, st, it, kkt = s.solve(d, warm=warm, state=state, state_out=so)
             torch.cuda.synchronize()
+            assert s.last_kernel_name() == KERNEL_NAMES[(kern, 4)]
             res.append((out.clone(), st.clone(), it.clone(), kkt.clone(), so.clone(), s.last_kernel_ms()))
         for x, y in zip(res[0][:5], res[1][:5]):
             assert torch.equal(x, y)
@@ -435,14 +506,13 @@ def test_pair_kernel_is_bitwise_the_single_wave_kernel(gpu, monkeypatch):
         b = both(spec, rec, warm=a[0][0], state=a[0][4])       # resumed
         if B == 1 and N == 20:
             assert a[1][5] < 0.85 * a[0][5], (a[0][5], a[1][5])  # and an instance alone on the GPU finishes sooner
-    monkeypatch.delenv("CMPC_PAIR")
     # the entry point picks the pair kernel by itself when the batch does not fill the GPU: same results either way
     spec, rec = wl.make_workload("randomized", B=64, N=20)
     auto = gpu(spec, device="cuda:0")
     o1, s1, i1, _ = auto.solve(torch.from_numpy(rec).cuda())
-    monkeypatch.setenv("CMPC_PAIR", "0")
-    single = gpu(spec, device="cuda:0")
+    single = gpu(dataclasses.replace(spec, kernel=KERNELS["single"]), device="cuda:0")
     o2, s2, i2, _ = single.solve(torch.from_numpy(rec).cuda())
     torch.cuda.synchronize()
+    assert auto.last_kernel_name() == KERNEL_NAMES[("pair", 4)] and single.last_kernel_name() == KERNEL_NAMES[("single", 4)]
     assert torch.equal(o1, o2) and torch.equal(i1, i2)
     assert auto.last_kernel_ms() < 0.9 * single.last_kernel_ms()

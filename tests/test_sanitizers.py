@@ -25,7 +25,7 @@ def test_emulated_kernel_and_oracle_are_clean_under_asan_ubsan(tmp_path):
         pytest.skip("gcc sanitizer runtimes not installed")
     emu_so, ora_so = str(tmp_path / "libcmpc_emu_asan.so"), str(tmp_path / "libcmpc_oracle_asan.so")
     flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fPIC", "-shared"]
-    subprocess.check_call(["g++", "-std=c++17", "-pthread"] + flags + ["-o", emu_so, os.path.join(ROOT, "tests", "emu", "cmpc_emu.cpp")])
+    subprocess.check_call(["g++", "-std=c++17", "-pthread", "-mfma", "-ffp-contract=off"] + flags + ["-o", emu_so, os.path.join(ROOT, "tests", "emu", "cmpc_emu.cpp")])
     subprocess.check_call(["gcc"] + flags + ["-o", ora_so, os.path.join(ROOT, "oracle", "cmpc_oracle.c"), "-lm"])
     env = dict(os.environ, LD_PRELOAD=f"{asan}:{ubsan}", ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")

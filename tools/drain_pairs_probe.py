@@ -16,8 +16,9 @@ spec, rec = wl.make_workload("randomized", B=B)
 order = np.argsort(-qo.bucket_of(qo.predicted_iterations(rec, spec)), kind="stable")
 rec = np.ascontiguousarray(rec[order])
 dev = "cuda:0"
-os.environ["CMPC_PAIR"] = "0"; sa = BatchedCentroidalMPC(spec, device=dev)
-os.environ["CMPC_PAIR"] = "1"; sb = BatchedCentroidalMPC(spec, device=dev)
+import dataclasses
+sa = BatchedCentroidalMPC(dataclasses.replace(spec, kernel=1), device=dev)      # cmpc_spec.kernel: one wavefront per instance
+sb = BatchedCentroidalMPC(dataclasses.replace(spec, kernel=2), device=dev)      # the pipelined pair
 d = torch.from_numpy(rec).to(dev)
 s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
 for X in xs:

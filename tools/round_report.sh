@@ -19,8 +19,8 @@ echo "wbc profile done"
 python tools/tail_study.py randomized 8192 > "$out/tail_randomized.txt" 2>&1
 python tools/tail_study.py long_horizon 2048 > "$out/tail_long_horizon.txt" 2>&1
 python bench.py --seed 777 --steps 6 --warmup 1 --no-extras --no-cpu-baseline > "$out/bench_line_seed777.json" 2>/dev/null
-CMPC_PAIR=0 python bench.py --workload perturbed --batch 256 --steps 6 --warmup 1 --no-extras --no-cpu-baseline > "$out/bench_line_perturbed_single_wave.json" 2>/dev/null
-(python tools/small_batch_latency.py randomized 1 16 256 && CMPC_PAIR=0 python tools/small_batch_latency.py randomized 1 16 256) 2>&1 | grep -v amdgpu.ids > "$out/small_batch_latency.txt"
+python bench.py --kernel single --workload perturbed --batch 256 --steps 6 --warmup 1 --no-extras --no-cpu-baseline > "$out/bench_line_perturbed_single_wave.json" 2>/dev/null
+(python tools/small_batch_latency.py randomized 1 16 256 && KERNEL=single python tools/small_batch_latency.py randomized 1 16 256) 2>&1 | grep -v amdgpu.ids > "$out/small_batch_latency.txt"
 python tools/walk_demo.py > "$out/walk_demo.txt" 2>&1; tail -2 "$out/walk_demo.txt"
 python tools/parity_report.py > "$out/parity_report.txt" 2>&1; echo "parity report done"
 for w in "randomized 8192" "payload 4096" "perturbed 4096"; do python tools/full_parity.py $w; done > "$out/full_parity.txt" 2>&1; tail -4 "$out/full_parity.txt"
