@@ -60,6 +60,8 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 // across the whole solve and spilled)
 #define CMPC_OPAQUE(x) asm volatile("" : "+v"(x))
 #define CMPC_OPAQUE_D(x) asm volatile("" : "+v"(x))
+// a wave-uniform integer the compiler cannot prove uniform: said so, it lives in a scalar register
+#define CMPC_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
 // nothing is scheduled across this point (keeps a batch of loads, its wait and its arithmetic together: left to itself
 // the scheduler parks the loaded words and spills them)
 #define CMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -88,6 +90,9 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 #define CMPC_FMA(x, y, z) __builtin_fma((x), (y), (z))
 #ifndef CMPC_OPAQUE_D
 #define CMPC_OPAQUE_D(x) do { } while (0)
+#endif
+#ifndef CMPC_UNIFORM_INT
+#define CMPC_UNIFORM_INT(x) (x)
 #endif
 
 // Optional phase timers (diagnostic build only, -DCMPC_PROFILE): cycles per phase summed over the
@@ -1086,13 +1091,23 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     double *M = &L(D::oM);
     double val[CNT], old[CNT];
     if constexpr (RMW) lds_read_tri12<I0>(old, M + lane);                   // M[tri(I0 + r) + lane] (right of the diagonal: a harmless word)
-    gt_vals<I0>(std::make_integer_sequence<int, CNT>{}, val, tc, cf, cv, ck, cd, cdm);
+    // (four rows at a time: the broadcast coefficients of a row are six scalar registers, and the scheduler would otherwise
+    // fetch those of the whole batch up front -- the scalar file overflows into vector registers, and those into scratch)
+    constexpr int SUB = 4;
+    static_assert(CNT % SUB == 0, "whole sub-batches");
 #pragma unroll
-    for (int r = 0; r < CNT; ++r) {
-      if constexpr (RMW) CMPC_OPAQUE_D(val[r]);              // (rounded before the add, as where it is stored first: see build_H_row)
-      if (lane <= I0 + r) M[tri(I0 + r) + lane] = RMW ? old[r] + val[r] : val[r];
+    for (int r0 = 0; r0 < CNT; r0 += SUB) {
+      double *v4 = val + r0;
+      if (r0 == 0) gt_vals<I0>(std::make_integer_sequence<int, SUB>{}, *reinterpret_cast<double (*)[SUB]>(v4), tc, cf, cv, ck, cd, cdm);
+      else if (r0 == SUB) gt_vals<I0 + SUB>(std::make_integer_sequence<int, SUB>{}, *reinterpret_cast<double (*)[SUB]>(v4), tc, cf, cv, ck, cd, cdm);
+      else gt_vals<I0 + 2 * SUB>(std::make_integer_sequence<int, SUB>{}, *reinterpret_cast<double (*)[SUB]>(v4), tc, cf, cv, ck, cd, cdm);
+#pragma unroll
+      for (int r = r0; r < r0 + SUB; ++r) {
+        if constexpr (RMW) CMPC_OPAQUE_D(val[r]);            // (rounded before the add, as where it is stored first: see build_H_row)
+        if (lane <= I0 + r) M[tri(I0 + r) + lane] = RMW ? old[r] + val[r] : val[r];
+      }
+      CMPC_SCHED_FENCE();
     }
-    CMPC_SCHED_FENCE();
   }
   template <bool RMW> CMPC_DEV void gt_phase(double gl, double gr, double m) {
     static_assert(D::GT && NH == 1 && NXA == 28 && NZ % GT_ROWS == 0, "one-wave 4-vertex solver");
@@ -2391,6 +2406,11 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     if (state_out && lane == 0) GArr{state_out}[D::state_mu(N)] = 0.0;     // invalid until a snapshot is taken
     double mu = resume ? st_in[D::state_mu(N)] : MU_INIT;
     kkt = INFINITY; st = CMPC_MAX_ITER;
+    // The counters of the outer loop (acceptable-level run, progress watch, polish steps left, collapsed steps).  One-wave
+    // workgroups keep them in four words of LDS (oCOLD + 4 .. 7, which only the two-wave solver's reductions use): in
+    // registers they are live across the whole sweep and were what the kernel spilled.  Read into locals with the other
+    // cold state -- every lane reads before any lane writes --, written back before the vector sweeps.
+    constexpr bool CNT_LDS = (NW == 1);
     int n_acc = 0, n_stall = 0, polish = -1, since_best = 0;
     bool use_saved = false;
     // cold scalars of the outer loop live in LDS (every lane reads the same word; written by every lane with the
@@ -2401,6 +2421,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       double inf = INFINITY, zero = 0.0;        // (materialised here: hoisted out of the instance loop they were spilled)
       CMPC_OPAQUE_D(inf); CMPC_OPAQUE_D(zero);
       reg_last = zero; kkt_best = inf; kkt_saved = inf; snapped = zero;
+      if constexpr (CNT_LDS) { R(D::oCOLD + 4) = zero; R(D::oCOLD + 5) = zero; R(D::oCOLD + 6) = zero - 1.0; R(D::oCOLD + 7) = zero; }
     }
     // acceptable level; every iterate the acceptable-level counter counts is also saved (see the oracle).  Formed
     // where they are used (two instructions) instead of being kept live across the solve.
@@ -2448,6 +2469,9 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       const double ebar = fmax(fmax(e_d / sd, e_p), e_cmu / sd);   // error of the barrier problem at mu
       double ks = kkt_saved, kb = kkt_best;     // cold state: every lane reads before any lane writes
       const bool unsnapped = snapped == 0.0;
+      if constexpr (CNT_LDS) {
+        n_acc = (int)R(D::oCOLD + 4); since_best = (int)R(D::oCOLD + 5); polish = (int)R(D::oCOLD + 6); n_stall = (int)R(D::oCOLD + 7);
+      }
       if constexpr (PIPE) { CMPC_SYNC_WG(); } else sync();
       if (polish >= 0 && kkt > ACC_FACTOR * tol) {
         // polishing lost ground (the step at the final barrier value needed an inertia correction): the point
@@ -2484,7 +2508,9 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       }
       // a resumed solve still at the state's barrier value: the state does not fit this tick's problem
       const bool stale = resume && it >= RESUME_RECENTRE_ITERS && polish < 0 && mu == st_in[D::state_mu(N)];
-      const bool at_cap = it == sp.max_iter - spent;
+      int it_cap = sp.max_iter - spent;         // (formed here: hoisted to the loop header it sat in a register across the sweep -- spilled)
+      CMPC_OPAQUE(it_cap);
+      const bool at_cap = it == it_cap;
       if (at_cap || !(kkt < INFINITY) || n_stall >= STALL_ITERS || stale) {
         if (polish >= 0) st = CMPC_CONVERGED;                   // (cap reached inside the polish)
         else if (ks <= acc_tol() && !stale) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; }
@@ -2505,24 +2531,35 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         // this iterate solves the barrier problem at mu_before: the state the next tick resumes from
         if (state_out && mu_before >= MU_WARM && mu < MU_WARM && unsnapped) { if (!PIPE || wv == 0) write_state(state_out, mu_before); snapped = 1.0; }
       }
+      if constexpr (CNT_LDS) { R(D::oCOLD + 4) = (double)n_acc; R(D::oCOLD + 5) = (double)since_best; R(D::oCOLD + 6) = (double)polish; }
       double ap, ad;
+      // (n_stall: read, barrier, written -- no lane may see the new count where it expects the old one)
+      auto count_stall = [&]() {
+        if constexpr (CNT_LDS) {
+          const int ns = (int)R(D::oCOLD + 7);
+          if constexpr (PIPE) { CMPC_SYNC_WG(); } else sync();
+          R(D::oCOLD + 7) = (ap < STALL_STEP) ? (double)(ns + 1) : 0.0;
+        } else n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
+      };
       if constexpr (PIPE) {
         vector_sweeps(mu, mu - mu_sweep, ap, ad);   // wave 0: du, dx, lam; wave 1: ds, dz, step bounds
+        count_stall();
         apply_step(mu, ap, ad);                     // wave 0: x, lam, u; wave 1: s, z
         pair_sync();                                // the new iterate (global) reaches the other wave
-        n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
       } else {
         vector_sweeps(mu, mu - mu_sweep, ap, ad);
         CMPC_TICK(6);
-        n_stall = (ap < STALL_STEP) ? n_stall + 1 : 0;
+        count_stall();
         apply_step(mu, ap, ad);
         CMPC_TICK(7);
       }
     }
     if (!use_saved && (!PIPE || wv == 0)) write_solution(out);
-    if (!(resume && (st == CMPC_MAX_ITER || st == CMPC_NUMERICAL))) break;
-    if (it >= sp.max_iter) break;               // nothing left of the budget
-    spent += it; resume = false;
+    // (the verdict is the same in every lane; said so, the attempt loop is a uniform loop and what it carries -- the
+    // iterations spent -- lives in a scalar register instead of a spilled vector one)
+    const int again = CMPC_UNIFORM_INT((int)(resume && (st == CMPC_MAX_ITER || st == CMPC_NUMERICAL) && it < sp.max_iter));
+    if (!again) break;                          // done, or nothing left of the budget
+    spent = CMPC_UNIFORM_INT(spent + it); resume = false;
     if constexpr (PIPE) pair_sync(); else gsync();
     }
     if (lane == 0 && (!PIPE || wv == 0)) {

@@ -131,52 +131,77 @@ def solve(spec, par, w0=None, u_prox=None, tol=1e-9, max_iter=300, verbose=False
     return dict(w=w, iters=it, kkt=kkt, status=status, lam=lam, z=z, s=s)
 
 
-def refine_active_set(spec, par, r, u_prox=None, act_tol=1e-6, iters=8, verbose=False):
-    """Newton's method on the KKT conditions of the ACTIVE-SET problem at an interior-point answer `r` (the dict `solve`
-    returns): the inequality rows whose multiplier dominates their slack are held as equalities, the others are dropped.
-    Without the barrier's z/s conditioning the iteration converges quadratically to the stationary point the interior
-    point was approaching, to rounding level -- which is what pins the directions the NLP leaves almost flat (curvature
-    = the 1e-4 proximal weight: a KKT error of 1e-9 determines them to 1e-5 only).  Still dense, still autograd
-    derivatives of the literal restatement; nothing of the C oracle or of the HIP solver.  Returns dict(w, lam, z, kkt,
-    active, ok): ok = the active-set point is a KKT point of the full problem (inactive rows satisfied, active
-    multipliers non-negative)."""
+def refine_active_set(spec, par, r, u_prox=None, s_max=1e-9, rounds=40, verbose=False):
+    """Primal-dual active-set refinement of an interior-point answer `r` (the dict `solve` returns): Newton's method on the
+    KKT conditions with a working set of inequality rows held as equalities, the others dropped, and the working set
+    corrected between Newton solves -- a violated row comes in, a row with a negative multiplier goes out, and of a group
+    of rows that cannot all hold as equalities (the five rows of a vertex at the apex of its friction cone, 5e-9 apart
+    through the 1e-8 relaxation) the one with the smallest multiplier goes out.  Without the barrier's z / s conditioning the
+    iteration converges to the stationary point the interior point was approaching, to rounding level -- which is what
+    pins the directions the NLP leaves almost flat (curvature = the 1e-4 proximal weight: a KKT error of 1e-9 determines
+    them to 1e-5 only).  Still dense, still autograd derivatives of the literal restatement; nothing of the C oracle or of
+    the HIP solver.  Returns dict(w, lam, z, kkt, active, ok): `ok` CERTIFIES the answer whatever path led to it --
+    stationarity and the working rows to 1e-10 (scaled as the solvers scale their KKT error), every other row satisfied
+    to 1e-12, every multiplier non-negative."""
     w, lam = np.array(r["w"], dtype=np.float64), np.array(r["lam"], dtype=np.float64)
-    g0 = nlp.inequalities(spec, par, torch.tensor(w)).numpy()
     z0, s0 = np.asarray(r["z"]), np.asarray(r["s"])
-    active = z0 > s0                                    # complementarity s z = mu: the active rows have z >> s
-    za = z0[active].copy()
+    # first guess.  Complementarity s z = mu: an active row has s = mu / z* -> 0; a row inactive by a hair keeps its slack and
+    # z = mu / s, which at mu = 1e-10 is still larger than s: rows with a slack above s_max start outside the working set.
+    active = (z0 > s0) & (s0 < s_max)
+    zfull = np.where(active, z0, 0.0)
     nw = w.size
-    kkt = np.inf
-    for it in range(iters):
+    kkt, ok = np.inf, False
+
+    def derivatives(w, lam, za, active):
         wt = torch.tensor(w, requires_grad=True)
         gradf = torch.autograd.grad(nlp.cost(spec, par, wt, u_prox), wt)[0].numpy()
         Jc = torch.autograd.functional.jacobian(lambda v: nlp.equalities(spec, par, v), wt.detach(), vectorize=True).numpy()
-        Jg = torch.autograd.functional.jacobian(lambda v: nlp.inequalities(spec, par, v), wt.detach(), vectorize=True).numpy()[active]
-        c = nlp.equalities(spec, par, wt.detach()).numpy()
-        g = nlp.inequalities(spec, par, wt.detach()).numpy()
-        lam_t, z_t = torch.tensor(lam), torch.tensor(za)
-        idx = torch.tensor(np.flatnonzero(active))
+        Jg = torch.autograd.functional.jacobian(lambda v: nlp.inequalities(spec, par, v), wt.detach(), vectorize=True).numpy()
+        lam_t, z_t, idx = torch.tensor(lam), torch.tensor(za), torch.tensor(np.flatnonzero(active))
 
         def lagr(v):
             return (nlp.cost(spec, par, v, u_prox) + (lam_t * nlp.equalities(spec, par, v)).sum()
                     + (z_t * nlp.inequalities(spec, par, v)[idx]).sum())
         H = torch.autograd.functional.hessian(lagr, wt.detach(), vectorize=True).numpy()
-        rd = gradf + Jc.T @ lam + Jg.T @ za
-        rp = np.concatenate([c, g[active]])
-        sd = max(100.0, (np.abs(lam).sum() + np.abs(za).sum()) / max(1, lam.size + za.size)) / 100.0
-        kkt = max(np.abs(rd).max() / sd, np.abs(rp).max())
+        return gradf, Jc, Jg, H
+
+    for rnd in range(rounds):
+        za = zfull[active]
+        for it in range(3):
+            gradf, Jc, Jg, H = derivatives(w, lam, za, active)
+            c = nlp.equalities(spec, par, torch.tensor(w)).numpy()
+            g = nlp.inequalities(spec, par, torch.tensor(w)).numpy()
+            A = np.vstack([Jc, Jg[active]])
+            rd = gradf + Jc.T @ lam + Jg[active].T @ za
+            rp = np.concatenate([c, g[active]])
+            sd = max(100.0, (np.abs(lam).sum() + np.abs(za).sum()) / max(1, lam.size + za.size)) / 100.0
+            kkt = max(np.abs(rd).max() / sd, np.abs(rp).max())
+            if kkt < 1e-13:
+                break
+            K = np.block([[H, A.T], [A, np.zeros((A.shape[0], A.shape[0]))]])
+            sol = np.linalg.lstsq(K, -np.concatenate([rd, rp]), rcond=1e-14)[0]
+            w = w + sol[:nw]
+            lam = lam + sol[nw:nw + lam.size]
+            za = za + sol[nw + lam.size:]
+        zfull = np.zeros_like(z0)
+        zfull[active] = za
+        g = nlp.inequalities(spec, par, torch.tensor(w)).numpy()
+        c = nlp.equalities(spec, par, torch.tensor(w)).numpy()
+        viol = np.flatnonzero(~active & (g > 1e-12))
+        neg = np.flatnonzero(active & (zfull < -1e-10))
+        stuck = np.flatnonzero(active & (np.abs(g) > 1e-11))
         if verbose:
-            print(f"   refine {it}: dual {np.abs(rd).max() / sd:.2e} primal {np.abs(rp).max():.2e} active {int(active.sum())}")
-        if kkt < 1e-13:
+            print(f"   refine round {rnd}: kkt {kkt:.2e} working rows {int(active.sum())}, violated outside {viol.size}, "
+                  f"negative multipliers {neg.size}, rows that cannot hold {stuck.size}", flush=True)
+        if viol.size == 0 and neg.size == 0 and stuck.size == 0 and kkt < 1e-10 and np.abs(c).max() < 1e-10:
+            ok = True
             break
-        A = np.vstack([Jc, Jg])
-        K = np.block([[H, A.T], [A, np.zeros((A.shape[0], A.shape[0]))]])
-        sol = np.linalg.lstsq(K, -np.concatenate([rd, rp]), rcond=1e-14)[0]
-        w = w + sol[:nw]
-        lam = lam + sol[nw:nw + lam.size]
-        za = za + sol[nw + lam.size:]
-    g = nlp.inequalities(spec, par, torch.tensor(w)).numpy()
-    ok = bool(kkt < 1e-10 and (za > -1e-9).all() and (g[~active] < 1e-9).all())
-    z = np.zeros_like(z0)
-    z[active] = za
+        if viol.size:                                           # most violated row first, one per vertex group at most
+            active[viol[np.argmax(g[viol])]] = True
+        elif neg.size:
+            active[neg[np.argmin(zfull[neg])]] = False
+        elif stuck.size:
+            active[stuck[np.argmin(zfull[stuck])]] = False
+        # (else: the working set stands, Newton goes on)
+    z = zfull
     return dict(w=w, lam=lam, z=z, kkt=kkt, active=active, ok=ok)
