@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(64 * NW, (NV == 4 ? CMPC_WAVES_PER_SIMD : 1)) 
 }
 
 // The pipelined pair (cmpc::Solver<4, 1, true>): two waves per instance, two LDS images.  For batches that do not keep
-// the GPU full for long (cmpc_solve_batch picks it up to 20 instances per CU): same results bit for bit, an instance
+// the GPU full for long (cmpc_solve_batch picks it up to 14 instances per CU): same results bit for bit, an instance
 // finishes ~1.55x sooner.  WPS = waves per SIMD the build is for: 2 (256 registers, three pairs per CU) or 1.
 template <int NV, int WPS>
 __global__ void __launch_bounds__(128, WPS) cmpc_solve_pair_kernel(cmpc::KArgs ka, int *ticket,
@@ -363,10 +363,10 @@ int cmpc_create(const cmpc_spec *spec, int device, cmpc_handle **out) {
     h->pair_grid = h->num_cu * h->pair_per_cu;
     // The pair kernel is the faster one while the queue is short (an instance-iteration takes 0.4 - 0.5 ms in a pair
     // against 0.65 - 1.2 ms in one of two to six single waves of a CU, and a short queue is mostly its longest instance).
-    // Measured crossover on 256 CUs: between 6144 and 7168 instances (config 4), 4096 and 6144 (config 3) with three pairs
-    // per CU; between 2048 and 2560 with two (profiles/r04h_pair_crossover.txt, r04m_pair3_crossover.txt).  The caller
-    // can fix the choice when the handle is created (cmpc_spec.kernel): the results are the same bit for bit.
-    h->pair_max_batch = (h->pair_per_cu >= 3 ? 20 : 8) * h->num_cu;
+    // Measured crossover on 256 CUs with seven one-wave workgroups against three pairs per CU (round 5): between 3072 and
+    // 4096 instances on configs 3 and 4 (profiles/r05_kernel_crossover.txt; round 4, six against three: 6144 ... 7168).  The
+    // caller can fix the choice when the handle is created (cmpc_spec.kernel): the results are the same bit for bit.
+    h->pair_max_batch = (h->pair_per_cu >= 3 ? 14 : 8) * h->num_cu;
     if (spec->kernel == CMPC_KERNEL_SINGLE) h->pair_max_batch = 0;
     if (spec->kernel == CMPC_KERNEL_PAIR) h->pair_max_batch = 1 << 30;
 #ifdef CMPC_DEV_KNOBS

@@ -1054,9 +1054,13 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     constexpr int s = I - NU;
     if constexpr (I >= NU && s < CMPC_NX) v = tc[s];
     if constexpr (gt_dense<I>()) {
-      // (lane I holds the column's dense entries in its list: two v_readlane per word, no LDS)
-      const double g0 = CMPC_BCAST(lg[0][1], I), g1 = CMPC_BCAST(lg[0][2], I), g2 = CMPC_BCAST(lg[0][3], I);
-      v = CMPC_FMA(g0, tc[6], v); v = CMPC_FMA(g1, tc[7], v); v = CMPC_FMA(g2, tc[8], v);
+      // (lane I holds the column's dense entries in its list: two v_readlane per word, no LDS.  A force column and a CoM /
+      // foot-position column hold a cross product with a unit vector, d gamma (r x e_a) resp. -+d (F x e_a): the entry of
+      // row 6 + a is an exact zero -- stage_geometry forms it as c (x 0 - y 0) -- and is left out; the yaw columns are dense)
+      constexpr int ax = is_f ? I % 3 : (s < 3) ? s : (s == 12 || s == 16) ? -1 : (s - 13) % 4;
+      if constexpr (ax != 0) { const double g0 = CMPC_BCAST(lg[0][1], I); v = CMPC_FMA(g0, tc[6], v); }
+      if constexpr (ax != 1) { const double g1 = CMPC_BCAST(lg[0][2], I); v = CMPC_FMA(g1, tc[7], v); }
+      if constexpr (ax != 2) { const double g2 = CMPC_BCAST(lg[0][3], I); v = CMPC_FMA(g2, tc[8], v); }
     }
     if constexpr (is_f) {
       constexpr int vtx = I / 3, a = I % 3, f = vtx / NV;
@@ -1101,11 +1105,14 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       if (r0 == 0) gt_vals<I0>(std::make_integer_sequence<int, SUB>{}, *reinterpret_cast<double (*)[SUB]>(v4), tc, cf, cv, ck, cd, cdm);
       else if (r0 == SUB) gt_vals<I0 + SUB>(std::make_integer_sequence<int, SUB>{}, *reinterpret_cast<double (*)[SUB]>(v4), tc, cf, cv, ck, cd, cdm);
       else gt_vals<I0 + 2 * SUB>(std::make_integer_sequence<int, SUB>{}, *reinterpret_cast<double (*)[SUB]>(v4), tc, cf, cv, ck, cd, cdm);
+      // (opaque: the four rows' chains are formed here, interleaved, instead of each being sunk into its own masked block
+      // behind a branch; RMW: also rounded before the add, as where it is stored first -- see build_H_row.  Lanes right of
+      // the diagonal write to their dump slot: an address select instead of an exec-mask round trip per row)
 #pragma unroll
-      for (int r = r0; r < r0 + SUB; ++r) {
-        if constexpr (RMW) CMPC_OPAQUE_D(val[r]);            // (rounded before the add, as where it is stored first: see build_H_row)
-        if (lane <= I0 + r) M[tri(I0 + r) + lane] = RMW ? old[r] + val[r] : val[r];
-      }
+      for (int r = r0; r < r0 + SUB; ++r) CMPC_OPAQUE_D(val[r]);
+      double *dump = &L(D::oDUMP + (lane & (D::DUMPN - 1)));
+#pragma unroll
+      for (int r = r0; r < r0 + SUB; ++r) *((lane <= I0 + r) ? &M[tri(I0 + r) + lane] : dump) = RMW ? old[r] + val[r] : val[r];
       CMPC_SCHED_FENCE();
     }
   }

@@ -161,8 +161,12 @@ def main():
             print(f"{name}: active-set Newton refinement kkt {rr['kkt']:.2e} ok {rr['ok']} active rows {int(rr['active'].sum())} "
                   f"|w - ipm_dense| {np.abs(rr['w'] - r['w']).max():.2e} {time.time() - t0:.0f} s", flush=True)
             if rr["ok"]:
+                # kkt_scale: the s_d of the scaled KKT error at this optimum (mean multiplier magnitude / 100, at least 1): a
+                # solver that meets a scaled tolerance tol has a dual residual of tol * kkt_scale, which along the directions
+                # the NLP leaves flat (curvature rho = 1e-4) is a displacement of tol * kkt_scale / rho
+                mult = np.concatenate([np.abs(rr["lam"]), np.abs(rr["z"][rr["active"]])])
                 out.update(sol_ipm_dense_unrefined=r["w"], ipm_dense_kkt_unrefined=r["kkt"], sol_ipm_dense=rr["w"],
-                           ipm_dense_kkt=rr["kkt"], ipm_dense_refined=1)
+                           ipm_dense_kkt=rr["kkt"], ipm_dense_refined=1, kkt_scale=max(100.0, mult.sum() / mult.size) / 100.0)
                 r = dict(r, w=rr["w"], kkt=rr["kkt"])
         if name in LINE_SEARCH_CASES:
             # the same solver with its l1-merit backtracking line search switched on: recorded for the

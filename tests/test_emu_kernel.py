@@ -27,7 +27,7 @@ def _emu_solve(emu, cs, rec, warm=None):
 
 
 def test_lds_budget(emu):
-    assert emu.cmpc_emu_lds_bytes(4) + 8 <= 26880           # 6 workgroups per CU (160 KiB LDS in 1280-byte granules)
+    assert emu.cmpc_emu_lds_bytes(4) + 8 <= 23040           # 7 workgroups per CU (160 KiB LDS in 1280-byte granules)
     assert emu.cmpc_emu_lds_bytes(8) <= 80 * 1024           # 2 workgroups per CU
 
 

@@ -137,7 +137,7 @@ def test_parity_with_oracle(gpu, oracle, name, B, N, rate, kernel):
 
 
 def test_parity_sample_from_a_launch_beyond_the_pair_threshold(gpu, oracle):
-    """The library's own choice at the bench's batch size (B = 8192 > 20 instances per CU) is the one-wavefront kernel with
+    """The library's own choice at the bench's batch size (B = 8192 > 14 instances per CU) is the one-wavefront kernel with
     its ticket queue running well past the resident grid: a sample of that launch -- early and late queue positions --
     against the oracle, same levels as above."""
     spec, rec = wl.make_workload("randomized", B=8192, N=20)
@@ -190,6 +190,21 @@ def test_independent_pins(gpu, oracle, path, kernel):
     assert (st[0] == 0 and kkt[0] < 1e-7) or (st[0] == 3 and kkt[0] <= 1e-8), (st, kkt)
     cs = oracle_spec(oracle, spec)
     check_against_pin(pin, got[0], lambda w: oracle.evaluate(cs, pin["record"], w), kkt=float(kkt[0]))
+
+
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_flat_directions_of_the_pinned_optimum_converge_with_the_tolerance(gpu, oracle, kernel):
+    """tests/test_independent_pins.py::flat_convergence for the HIP solver: on the N = 20 touch-down pin (refined to 2e-11)
+    the foot-velocity group moves towards the pin as the tolerance is tightened from 1e-9 to 1e-10."""
+    from test_independent_pins import flat_convergence
+    pin = np.load(os.path.join(GOLD, "independent_pin_N20_t255_switch.npz"))
+
+    def solve_at(tol, acc_tol):
+        spec = ProblemSpec(N=int(pin["N"]), nv=int(pin["nv"]), k1=float(pin["k1"]), k2=float(pin["k2"]), tol=tol, max_iter=200, acc_tol=acc_tol)
+        got, st, it, kkt = _solve(gpu, spec, pin["record"][None, :], kernel=kernel)
+        assert st[0] in (0, 3), (st, kkt)
+        return got[0]
+    flat_convergence(solve_at, pin)
 
 
 @pytest.mark.parametrize("kernel", ["single", "pair"])

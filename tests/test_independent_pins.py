@@ -58,12 +58,19 @@ def check_against_pin(pin, sol, evaluate, kkt=0.0):
         assert rel_inf(sol, pin["sol_ipm_dense"])[0] < lim and det < lim
         f_s, f_d = evaluate(sol)[0], evaluate(pin["sol_ipm_dense"])[0]
         assert abs(f_s - f_d) <= 1e-9 * abs(f_d)
+        # The foot-velocity inputs (and the foot poses they integrate to).  Round 5 regenerated the one pin whose dense solve
+        # had stopped at a KKT error of 6e-9 (N = 20, touch-down inside the horizon: refined by Newton's method on its active
+        # set to 2e-11, oracle/ipm_dense.py::refine_active_set) and measured what a SOLVER's tolerance determines there
+        # (the pin's multiplier scale s_d is 6.7e+3, stored as `kkt_scale`: a scaled KKT error of 1e-9 is a dual residual of
+        # 7e-6 against a curvature of 1e-4 along these directions).  Distance of the foot-velocity group from the refined pin
+        # at solver tolerances 1e-9 / 1e-10 / 1e-11: C oracle 5.0e-6 / 8.1e-7 / 8.2e-7, kernel source (host emulation)
+        # 6.0e-5 / 1.8e-5 / 1.2e-7, HIP kernel at 1e-9: 8.7e-5 -- the pin is the optimum, and a tolerance of 1e-9 fixes this
+        # group to ~1e-4.  Asserted: `lim` wherever the tolerance reaches it; beyond it only within 3e-4 (3 x the measured
+        # 8.7e-5; feet 3e-5) AND objective-neutral to 1e-9 (asserted above) AND dynamics satisfied -- the flat valley
+        # itself; test_flat_directions_converge_with_the_tolerance holds the solver to the trend.
         flat = flat_group_rel_inf(sol, pin["sol_ipm_dense"], N, nu)
         if flat >= lim or feet >= lim:
-            # further apart along the flat direction than `lim`: it must BE the flat direction -- the objective equal to
-            # 1e-9 (asserted above), the dynamics satisfied, the displacement small -- i.e. the same optimum seen from two
-            # points of its valley (the criterion of tests/test_gpu_parity.py::_explain_outliers)
-            assert flat < 1e-3 and feet < 1e-4 and np.abs(evaluate(sol)[1]).max() < 1e-7, (flat, feet, kkt)
+            assert flat < 3e-4 and feet < 3e-5 and np.abs(evaluate(sol)[1]).max() < 1e-7, (flat, feet, kkt)
         anchors += 1
     if "ipm_dense_ls_status" in pin.files and int(pin["ipm_dense_ls_status"]) == 0:   # same, l1 line search
         assert rel_inf(sol, pin["sol_ipm_dense_ls"])[0] < 1e-5
@@ -95,6 +102,29 @@ def test_pin_files_cover_the_walk():
     masses = {round(float(np.load(f)["record"][20]), 3) for f in FILES}
     mus = {round(float(np.load(f)["record"][21]), 3) for f in FILES}
     assert len(masses) >= 4 and {0.3, 0.9} <= mus
+
+
+def flat_convergence(solve_at, pin):
+    """The distance of the foot-velocity group from the pin at solver tolerances 1e-9 and 1e-10 (solve_at(tol, acc_tol) ->
+    solution): it must fall with the tolerance -- what is left at 1e-9 is the tolerance's, not a different optimum."""
+    N, nu = int(pin["N"]), 6 * int(pin["nv"]) + 8
+    f9 = flat_group_rel_inf(solve_at(1e-9, 1e-8), pin["sol_ipm_dense"], N, nu)
+    f10 = flat_group_rel_inf(solve_at(1e-10, 1e-9), pin["sol_ipm_dense"], N, nu)
+    assert f10 < 3e-5 and (f10 < 0.5 * f9 or f9 < 1e-5), (f9, f10)
+    return f9, f10
+
+
+def test_flat_directions_converge_with_the_tolerance(oracle):
+    pin = np.load(os.path.join(GOLD, "independent_pin_N20_t255_switch.npz"))
+    assert int(pin["ipm_dense_refined"]) == 1 and float(pin["ipm_dense_kkt"]) < 1e-10 and float(pin["kkt_scale"]) > 1e3
+
+    def solve_at(tol, acc_tol):
+        cs = oracle.default_spec(N=int(pin["N"]), nv=int(pin["nv"]), tol=tol, max_iter=200, k1=float(pin["k1"]), k2=float(pin["k2"]),
+                                 acc_tol=acc_tol)
+        sol, st, it, kkt = oracle.solve(cs, pin["record"])
+        assert st in (0, 3)
+        return sol
+    flat_convergence(solve_at, pin)
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[16:-4] for f in FILES])
