@@ -48,7 +48,8 @@ constexpr int oSIG = oZ + NI;                            // z / s (16)
 constexpr int oW = oSIG + NI;                            // mu / s + sigma * (A x + s) (16)
 constexpr int oRHS = oW + NI;                            // right-hand side / solution (48)
 constexpr int oL = oRHS + NK;                            // strictly lower part of L, packed: row i at tri(i)
-constexpr int LDS_DOUBLES = oL + NK * (NK + 1) / 2;
+constexpr int oC = oL + NK * (NK + 1) / 2;                // constant part of the trailing 18 x 18 block, lower triangle packed by rows
+constexpr int LDS_DOUBLES = oC + (NK - ND) * (NK - ND + 1) / 2 + 1;
 __device__ __forceinline__ constexpr int tri(int i) { return i * (i + 1) / 2; }
 
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // one wave per workgroup
@@ -143,6 +144,11 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__re
 #pragma unroll
         for (int k = j + 1; k < NK; ++k) {
           ac[k] -= lij * bcast(ac[j], k);                    // column j, still unscaled
+          // (opaque: the trailing words k >= ND are not read again before the loop is over, and hipcc sinks their thirty
+          // updates down to that point -- with the thirty broadcast multipliers of each parked in lanes of a vector
+          // register by v_writelane and fetched back: three instructions per word instead of one, 1100 of them per
+          // instance, and the vector registers holding them spilled to scratch)
+          if (k >= ND) asm volatile("" : "+v"(ac[k]));
           if ((k - j) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
         }
         ac[j] = (ln > j) ? lij : ac[j];
@@ -153,6 +159,15 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__re
 #pragma unroll
         for (int j = 0; j < ND; ++j)
           if (j < ln) L[oL + tl + j] = ac[j];
+      }
+      // ... and the constant Schur complement of the trailing block (rows ND .. NK-1, lower triangle): every Newton step
+      // starts its 18 x 18 factorisation from it.  Kept in LDS (171 words), not in 36 registers across the Newton loop --
+      // with the constant columns above that is the whole `ac` array out of the loop, and the kernel's spills with it.
+      if (ln >= ND && ln < NK) {
+        const int tc = tri(ln - ND);
+#pragma unroll
+        for (int t = 0; t < NK - ND; ++t)
+          if (t <= ln - ND) L[oC + tc + t] = ac[ND + t];
       }
       lds_fence();
     }
@@ -234,10 +249,11 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(int B, const double *__re
 #pragma unroll
       for (int r = 0; r < 8; ++r) wl[r] = wrench_entry(r, comp_l, dfoot, muf);
       double w[NT];
+      const double *crow = &L[oC + tri((ln >= ND && ln < NK) ? ln - ND : 0)];   // (other lanes' words are never used)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int j = ND + t;
-        double v = ac[j];
+        double v = crow[t];
         if (j < NX) {
           const int cj = (j - ND) % 6, fj = (j - ND) / 6;
           double acc = 0.0;

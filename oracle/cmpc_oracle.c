@@ -41,6 +41,9 @@
 #endif
 /* no progress at the final barrier value: NOPROG_ITERS iterations without halving the best KKT error
  * seen there.  The run then ends as CMPC_ACCEPTABLE as soon as the error is within spec.acc_tol. */
+#ifndef NOPROG_FACTOR              /* "progress" at a barrier value = the best error of that barrier problem fell below this share */
+#define NOPROG_FACTOR 0.5
+#endif
 #ifndef NOPROG_ITERS
 #define NOPROG_ITERS 12
 #endif
@@ -809,7 +812,7 @@ static void solve_one_capped(const cmpc_spec *sp, const double *rec, const doubl
            * residual oscillating at 1e-4 under an inertia correction: up to 85 iterations at mu = 1.8e-7 before the
            * cap) and end "acceptable" either way.  The watch restarts whenever the barrier value changes. */
           const double kw = (mu <= tol / 10) ? kkt : fmax(fmax(e_d / sd, e_p), e_cmu / sd);
-          if (kw < 0.5 * kkt_best) { kkt_best = kw; since_best = 0; } else ++since_best;
+          if (kw < NOPROG_FACTOR * kkt_best) { kkt_best = kw; since_best = 0; } else ++since_best;
           if (since_best >= NOPROG_ITERS && kkt_saved <= acc_tol) {
             st->status = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = 1; break;
           }
