@@ -197,14 +197,12 @@ template <int NV, int NW> struct Sizes {
   static constexpr int NPT = NXA * (NXA + 1) / 2;
 };
 
-// ---- LDS map (doubles), 8-vertex solver (one or two waves): M, the full symmetric P, the stage vectors, and a staging tile
-// of T = P [B A] in two column halves behind them.
+// ---- LDS map (doubles), 8-vertex solver (one or two waves): M, the full symmetric P, the stage vectors.  Round 5: G'PG out of
+// registers here too (Solver::gt_phase, Hessian rows first as in the pipelined pair): the staging tile of T = P [B A]
+// (36 x 47 doubles in two column halves) is gone; its place holds the 80 words of the factorisation's hand-off table.
 template <int NV, int NW, bool PIPE> struct LdsMap : Sizes<NV, NW> {
   using S = Sizes<NV, NW>;
-  static constexpr bool GT = false, GT_FIRST = false;
-  static constexpr int NPART = 2;
-  static constexpr int TH = (S::NZ + NPART - 1) / NPART;   // columns per part
-  static constexpr int TS = TH | 1;
+  static constexpr bool GT = true, GT_FIRST = false;
   static constexpr int oM = 0;
   static constexpr int oP = oM + S::NTRI + (S::NTRI & 1);
   static constexpr bool P_PACKED = false;
@@ -248,13 +246,9 @@ template <int NV, int NW, bool PIPE> struct LdsMap : Sizes<NV, NW> {
   static constexpr int oTV = oSK;
   static constexpr int oTV2 = oAL;
   static_assert(3 * S::NF <= S::NZ && S::NZ <= 2 * S::NI, "overlays fit");
-  static constexpr int oT = oEND;             // the staging tile of T = P [B A] (NXA x TS)
-  static constexpr int oUB = oT;              // in-block multiplier table of the factorisation (the T tile is dead there)
-  static_assert(oT % 2 == 0, "16-byte reads of the in-block table");
-  // (+ T_PAD: add_GtPG reads the T rows in batches of 10 columns whatever the row's length; the tail of the
-  // last row must still be inside the allocation)
-  static constexpr int T_PAD = 10;
-  static constexpr int LDS_DOUBLES = oEND + S::NXA * TS + T_PAD;
+  static constexpr int oUB = oEND + (oEND & 1);   // in-block multiplier table of the factorisation (64 words) + the second
+  static constexpr int LDS_DOUBLES = oUB + 80;    // wave's panel hand-off (11 words)
+  static_assert(oUB % 2 == 0, "16-byte reads of the in-block table");
 };
 
 // ---- LDS map (doubles), one-wave 4-vertex solver (round 5).  T = P [B A] is held one column per lane in REGISTERS and
@@ -324,7 +318,6 @@ template <bool PIPE> struct LdsMap<4, 1, PIPE> : Sizes<4, 1> {
   static_assert(oTV2 + S::NZ <= oLAMK && oTV + S::NZ <= oVDV && oUB + 64 <= oVDV && oUB % 2 == 0, "temporaries fit");
   static_assert(3 * S::NF <= S::NZ, "r_j fits");
   static constexpr int LDS_DOUBLES = oEND + (oEND & 1);
-  static constexpr int NPART = 1, TH = S::NZ, TS = S::NZ | 1, oT = oUB, T_PAD = 0;   // (no staging tile; names kept for shared code)
 };
 
 template <int NV, int NW = 1, bool PIPE = false> struct Dims : LdsMap<NV, NW, PIPE> {
@@ -1057,10 +1050,11 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       // (lane I holds the column's dense entries in its list: two v_readlane per word, no LDS.  A force column and a CoM /
       // foot-position column hold a cross product with a unit vector, d gamma (r x e_a) resp. -+d (F x e_a): the entry of
       // row 6 + a is an exact zero -- stage_geometry forms it as c (x 0 - y 0) -- and is left out; the yaw columns are dense)
+      // (two waves per instance: lane I may sit in the other wave -- the entries come as uniform reads of GH)
       constexpr int ax = is_f ? I % 3 : (s < 3) ? s : (s == 12 || s == 16) ? -1 : (s - 13) % 4;
-      if constexpr (ax != 0) { const double g0 = CMPC_BCAST(lg[0][1], I); v = CMPC_FMA(g0, tc[6], v); }
-      if constexpr (ax != 1) { const double g1 = CMPC_BCAST(lg[0][2], I); v = CMPC_FMA(g1, tc[7], v); }
-      if constexpr (ax != 2) { const double g2 = CMPC_BCAST(lg[0][3], I); v = CMPC_FMA(g2, tc[8], v); }
+      if constexpr (ax != 0) { const double g0 = (NW == 1) ? CMPC_BCAST(lg[0][1], I) : L(D::oGH + I); v = CMPC_FMA(g0, tc[6], v); }
+      if constexpr (ax != 1) { const double g1 = (NW == 1) ? CMPC_BCAST(lg[0][2], I) : L(D::oGH + NZ + I); v = CMPC_FMA(g1, tc[7], v); }
+      if constexpr (ax != 2) { const double g2 = (NW == 1) ? CMPC_BCAST(lg[0][3], I) : L(D::oGH + 2 * NZ + I); v = CMPC_FMA(g2, tc[8], v); }
     }
     if constexpr (is_f) {
       constexpr int vtx = I / 3, a = I % 3, f = vtx / NV;
@@ -1085,43 +1079,52 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     ((val[R] = gt_row<I0 + R>(tc, cf, cv, ck, cd, cdm)), ...);
   }
   static constexpr int GT_ROWS = 12;           // rows of M per batch (RMW: their old values come in one batch of LDS reads)
+  static constexpr int GT_FULL = NZ / GT_ROWS, GT_TAIL = NZ % GT_ROWS;      // 60 = 5 x 12;  92 = 7 x 12 + 8
+  static_assert(GT_TAIL == 0 || GT_TAIL == 8, "row batches of twelve and one of eight");
   template <bool RMW, int... G> CMPC_DEV void gt_groups(std::integer_sequence<int, G...>, const double (&tc)[D::NXA],
                                                         const double (&cf)[2], const double (&cv)[2], double ck, double cd, double cdm) {
-    (gt_rows<RMW, GT_ROWS * G>(tc, cf, cv, ck, cd, cdm), ...);
+    (gt_rows<RMW, GT_ROWS * G, GT_ROWS>(tc, cf, cv, ck, cd, cdm), ...);
+    if constexpr (GT_TAIL != 0) gt_rows<RMW, GT_ROWS * GT_FULL, GT_TAIL>(tc, cf, cv, ck, cd, cdm);
   }
-  template <bool RMW, int I0> CMPC_DEV void gt_rows(const double (&tc)[D::NXA], const double (&cf)[2], const double (&cv)[2],
-                                                    double ck, double cd, double cdm) {
-    constexpr int CNT = GT_ROWS;
+  template <bool RMW, int I0, int SUB, int... Q> CMPC_DEV void gt_subs(std::integer_sequence<int, Q...>, double *val, const double *old,
+                                                                       const double (&tc)[D::NXA], const double (&cf)[2],
+                                                                       const double (&cv)[2], double ck, double cd, double cdm) {
+    (gt_sub<RMW, I0 + SUB * Q, SUB>(val + SUB * Q, old + SUB * Q, tc, cf, cv, ck, cd, cdm), ...);
+  }
+  template <bool RMW, int I0, int SUB> CMPC_DEV void gt_sub(double *val, const double *old, const double (&tc)[D::NXA], const double (&cf)[2],
+                                                            const double (&cv)[2], double ck, double cd, double cdm) {
     double *M = &L(D::oM);
+    gt_vals<I0>(std::make_integer_sequence<int, SUB>{}, *reinterpret_cast<double (*)[SUB]>(val), tc, cf, cv, ck, cd, cdm);
+    // (opaque: the four rows' chains are formed here, interleaved, instead of each being sunk into its own masked block
+    // behind a branch; RMW: also rounded before the add, as where it is stored first -- see build_H_row.  Lanes right of
+    // the diagonal write to their dump slot: an address select instead of an exec-mask round trip per row)
+#pragma unroll
+    for (int r = 0; r < SUB; ++r) CMPC_OPAQUE_D(val[r]);
+    double *dump = &L(D::oDUMP + (lane & (D::DUMPN - 1)));
+#pragma unroll
+    for (int r = 0; r < SUB; ++r) *((lane <= I0 + r) ? &M[tri(I0 + r) + lane] : dump) = RMW ? old[r] + val[r] : val[r];
+    CMPC_SCHED_FENCE();
+  }
+  template <bool RMW, int I0, int CNT> CMPC_DEV void gt_rows(const double (&tc)[D::NXA], const double (&cf)[2], const double (&cv)[2],
+                                                             double ck, double cd, double cdm) {
+    // (two waves: the second wave's lanes are columns >= 64, which rows above 64 do not have)
+    if constexpr (NW == 2 && I0 + CNT <= 64) { if (wv != 0) return; }
     double val[CNT], old[CNT];
-    if constexpr (RMW) lds_read_tri12<I0>(old, M + lane);                   // M[tri(I0 + r) + lane] (right of the diagonal: a harmless word)
+    if constexpr (RMW) {                       // M[tri(I0 + r) + lane] (right of the diagonal: a harmless word)
+      if constexpr (CNT == 12) lds_read_tri12<I0>(old, &L(D::oM) + lane); else lds_read_tri8<I0>(old, &L(D::oM) + lane);
+    }
     // (four rows at a time: the broadcast coefficients of a row are six scalar registers, and the scheduler would otherwise
     // fetch those of the whole batch up front -- the scalar file overflows into vector registers, and those into scratch)
     constexpr int SUB = 4;
     static_assert(CNT % SUB == 0, "whole sub-batches");
-#pragma unroll
-    for (int r0 = 0; r0 < CNT; r0 += SUB) {
-      double *v4 = val + r0;
-      if (r0 == 0) gt_vals<I0>(std::make_integer_sequence<int, SUB>{}, *reinterpret_cast<double (*)[SUB]>(v4), tc, cf, cv, ck, cd, cdm);
-      else if (r0 == SUB) gt_vals<I0 + SUB>(std::make_integer_sequence<int, SUB>{}, *reinterpret_cast<double (*)[SUB]>(v4), tc, cf, cv, ck, cd, cdm);
-      else gt_vals<I0 + 2 * SUB>(std::make_integer_sequence<int, SUB>{}, *reinterpret_cast<double (*)[SUB]>(v4), tc, cf, cv, ck, cd, cdm);
-      // (opaque: the four rows' chains are formed here, interleaved, instead of each being sunk into its own masked block
-      // behind a branch; RMW: also rounded before the add, as where it is stored first -- see build_H_row.  Lanes right of
-      // the diagonal write to their dump slot: an address select instead of an exec-mask round trip per row)
-#pragma unroll
-      for (int r = r0; r < r0 + SUB; ++r) CMPC_OPAQUE_D(val[r]);
-      double *dump = &L(D::oDUMP + (lane & (D::DUMPN - 1)));
-#pragma unroll
-      for (int r = r0; r < r0 + SUB; ++r) *((lane <= I0 + r) ? &M[tri(I0 + r) + lane] : dump) = RMW ? old[r] + val[r] : val[r];
-      CMPC_SCHED_FENCE();
-    }
+    gt_subs<RMW, I0, SUB>(std::make_integer_sequence<int, CNT / SUB>{}, val, old, tc, cf, cv, ck, cd, cdm);
   }
   template <bool RMW> CMPC_DEV void gt_phase(double gl, double gr, double m) {
-    static_assert(D::GT && NH == 1 && NXA == 28 && NZ % GT_ROWS == 0, "one-wave 4-vertex solver");
+    static_assert(D::GT && NH == 1 && (NXA == 28 || NXA == 36), "one column of the stage block per lane");
     double tc[NXA];
 #pragma unroll
     for (int q = 0; q < NXA; ++q) tc[q] = 0.0;
-    {
+    if constexpr (D::P_PACKED) {
       const double *Pp = &R(D::oP);
 #pragma unroll
       for (int n = 0; n < 6; ++n) {
@@ -1151,107 +1154,31 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
           CMPC_SCHED_FENCE();                  //  instead of being sunk to the M phase with the loaded words kept -- and spilled -- until then)
         }
       }
+    } else {
+      // full symmetric P (8-vertex solver): column c is a strided read, eighteen words at a time
+      static_assert(D::P_PACKED || NXA == 36, "two batches of eighteen");
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        const double g = lg[0][n];
+        const double *pc = &R(D::oP + lr[0][n]);
+#pragma unroll
+        for (int q0 = 0; q0 < NXA; q0 += 18) {
+          double v[18];
+          lds_read_strided18<D::PS>(v, pc + q0 * D::PS);
+#pragma unroll
+          for (int q = 0; q < 18; ++q) { tc[q0 + q] = CMPC_FMA(g, v[q], tc[q0 + q]); CMPC_OPAQUE_D(tc[q0 + q]); }
+          CMPC_SCHED_FENCE();
+        }
+      }
     }
     if constexpr (D::GT_FIRST) sync();         // every lane has read its words of P: the region is free for the late vectors
     CMPC_TICK(10);
     const double d = sp.delta;
     const double cf[2] = {d * gl / m, d * gr / m}, cv[2] = {d * (1 - gl), d * (1 - gr)};
     const double ck = d * sp.k1 / m, cd = d, cdm = d / m;
-#ifdef CMPC_DEBUG_SKIP_GT                      // (diagnostic build: the Hessian rows alone in M)
-    if constexpr (!RMW) { for (int e = lane; e < D::NTRI; e += WS) L(D::oM + e) = 0.0; }
-#else
-    gt_groups<RMW>(std::make_integer_sequence<int, NZ / GT_ROWS>{}, tc, cf, cv, ck, cd, cdm);
-#endif
+    gt_groups<RMW>(std::make_integer_sequence<int, GT_FULL>{}, tc, cf, cv, ck, cd, cdm);
     sync();
     CMPC_TICK(14);
-  }
-
-  // M += [B A]' P [B A]  (lower triangle, row owner), using T = P [B A] staged by column halves.
-  CMPC_DEV void add_GtPG(double gl, double gr, double m) {
-    // Register-blocked in small tiles: within a tile every LDS read is independent of the others (one
-    // wave per SIMD has nothing else to hide the ~100-cycle LDS latency behind), and the tiles are
-    // small enough (<= 2 x 14 doubles live) that the allocator does not serialise the reads.
-    constexpr int QT = (NXA <= 28) ? NXA : NXA / 2;             // rows of T per tile
-    static_assert(QT == 28 || QT == 18 || QT == 14, "LDS batch-read helper sizes");
-    constexpr int CT = 10;                                      // columns of M per tile
-#pragma unroll 1
-    for (int half = 0; half < D::NPART; ++half) {
-      const int c0 = half * D::TH, c1 = (c0 + D::TH < NZ) ? c0 + D::TH : NZ;
-      auto t_rows = [&](const int col, const int q0, const int *cr, const double *cg) {   // T[q0 .. q0+QT)[col]
-        double acc[QT];
-#pragma unroll
-        for (int q = 0; q < QT; ++q) acc[q] = 0.0;
-#pragma unroll
-        for (int n = 0; n < 6; ++n) {
-          const double g = cg[n];
-          double v[QT];
-          const double *pc = &R(D::oP + q0 * D::PS + cr[n]);
-          if constexpr (QT == 28) lds_read_strided28<D::PS>(v, pc);
-          else if constexpr (QT == 18) lds_read_strided18<D::PS>(v, pc);
-          else lds_read_strided14<D::PS>(v, pc);
-#pragma unroll
-          for (int q = 0; q < QT; ++q) acc[q] += g * v[q];
-        }
-        double *tc = &L(D::oT + q0 * D::TS + (col - c0));
-#pragma unroll
-        for (int q = 0; q < QT; ++q) tc[q * D::TS] = acc[q];
-      };
-      if constexpr (NW == 1) {
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {         // column of T = P [B A] owned by this lane in this half
-          const int col = lane + WS * h;
-          if (col >= c0 && col < c1) {
-#pragma unroll 1
-            for (int q0 = 0; q0 < NXA; q0 += QT) t_rows(col, q0, lr[h], lg[h]);
-          }
-        }
-      } else {
-        // two waves: lane l of either wave takes column c0 + l of the half, the first wave its upper QT rows and the
-        // second the lower ones; the column's list is rebuilt on the spot (the lane's own list is another column's)
-        static_assert(NW == 1 || (D::TH <= 64 && NXA == 2 * QT), "one lane per column and row half");
-        const int col = c0 + (lane & 63);
-        if (col < c1) {
-          int cr[6];
-          double cg[6];
-          column_list(col, cr, cg, &L(D::oGH), gl, gr, m);
-          t_rows(col, wv * QT, cr, cg);
-        }
-      }
-      sync();
-      CMPC_TICK(10);
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {           // owned row of M, columns c0 .. min(row, c1-1)
-        const int rowi = lane + WS * h;
-        if (rowi >= c0 && rowi < NZ) {
-          const int iend = ((rowi < c1 - 1) ? rowi : c1 - 1) - c0;   // last column, relative to c0
-#pragma unroll 1
-          for (int i0 = 0; i0 <= iend; i0 += CT) {
-            double acc[CT];
-#pragma unroll
-            for (int i = 0; i < CT; ++i) acc[i] = 0.0;
-#pragma unroll
-            for (int n = 0; n < 6; n += 2) {   // tail columns read valid LDS, results unused
-              const double g0 = lg[h][n], g1 = lg[h][n + 1];
-              double va[CT], vb[CT];
-              lds_read_pair10(va, vb, &L(D::oT + lr[h][n] * D::TS + i0), &L(D::oT + lr[h][n + 1] * D::TS + i0));
-#pragma unroll
-              for (int i = 0; i < CT; ++i) acc[i] += g0 * va[i] + g1 * vb[i];
-            }
-            // masked-off columns are redirected to the lane's dump slot: per-element conditional
-            // stores compile to a divergent branch with an exposed LDS round trip each
-            double *row = &L(D::oM + tri(rowi) + c0 + i0), *dump = &L(D::oDUMP + (lane & (D::DUMPN - 1)));
-            double *pm[CT];
-            double old[CT];
-#pragma unroll
-            for (int i = 0; i < CT; ++i) { pm[i] = (i0 + i <= iend) ? row + i : dump; old[i] = *pm[i]; }
-#pragma unroll
-            for (int i = 0; i < CT; ++i) *pm[i] = old[i] + acc[i];
-          }
-        }
-      }
-      sync();
-      CMPC_TICK(14);
-    }
   }
 
   // Cholesky of the input block, Ls, Schur complement.  Returns false on a non-positive pivot.
@@ -1798,11 +1725,10 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       if constexpr (!D::GT_FIRST) {
         // Pb = P_{k+1} b  (needed by the vector sweep), then M += G'PG  (PIPE: P b is the other wave's, pair_vectors)
         if constexpr (!PIPE) form_Pb(st);
-        sync();                            // (8-vertex solver: the T tile of add_GtPG is its own region)
+        sync();
         CMPC_TICK(13);
         CMPC_RELANE(lane); CMPC_OPAQUE(lane);
-        if constexpr (D::GT) gt_phase<true>(L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
-        else add_GtPG(L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
+        gt_phase<true>(L(D::oSR + 17), L(D::oSR + 18), L(D::oHDR + 20));
         CMPC_TICK(14);
       }
       CMPC_RELANE(lane); CMPC_OPAQUE(lane);

@@ -115,15 +115,15 @@ extern "C" int cmpc_emu_solve_batch_state(const cmpc_spec *sp, int32_t B, const 
   ka.sp = *sp; ka.B = B; ka.recs = recs; ka.warm = warm; ka.out = out;
   ka.state_in = state_in; ka.state_out = state_out;
   ka.status = status; ka.iters = iters; ka.kkt = kkt; ka.prof = nullptr;
-  // CMPC_EMU_WAVES=1 runs the 8-vertex solver as one wave per instance (the product launches two)
-  const int nw8 = getenv("CMPC_EMU_WAVES") ? atoi(getenv("CMPC_EMU_WAVES")) : cmpc::WAVES_NV8;
-  if (nw8 != 1 && nw8 != 2) return 1;
-  const size_t nd = (sp->nv == 4) ? cmpc::Dims<4>::scratch_doubles(sp->N)
-                    : (nw8 == 2)  ? cmpc::Dims<8, 2>::scratch_doubles(sp->N) : cmpc::Dims<8>::scratch_doubles(sp->N);
+  // (the 8-vertex solver is a two-wave workgroup: round 5's G'PG keeps one column of the stage block per lane, which one
+  // wave of 64 lanes does not have for its 92 columns -- the one-wave form of rounds 2-4 is gone)
+  const int nw8 = cmpc::WAVES_NV8;
+  static_assert(cmpc::WAVES_NV8 == 2, "two waves");
+  const size_t nd = (sp->nv == 4) ? cmpc::Dims<4>::scratch_doubles(sp->N) : cmpc::Dims<8, 2>::scratch_doubles(sp->N);
   // CMPC_EMU_PAIR=1 runs the 4-vertex solver as the pipelined pair of waves (two LDS images + the exchange words)
   const bool pair = sp->nv == 4 && getenv("CMPC_EMU_PAIR") && atoi(getenv("CMPC_EMU_PAIR")) == 1;
   const size_t nl = pair ? 2 * cmpc::Dims<4, 1, true>::LDS_DOUBLES : (sp->nv == 4) ? cmpc::Dims<4>::LDS_DOUBLES
-                    : (nw8 == 2)  ? cmpc::Dims<8, 2>::LDS_DOUBLES : cmpc::Dims<8>::LDS_DOUBLES;
+                    : cmpc::Dims<8, 2>::LDS_DOUBLES;
   const double fill = getenv("CMPC_EMU_FILL") ? atof(getenv("CMPC_EMU_FILL")) : 0.0;
   std::vector<double> scratch(nd, fill), lds(nl, fill);
   ka.scratch = scratch.data(); ka.scratch_stride = nd;
@@ -132,12 +132,10 @@ extern "C" int cmpc_emu_solve_batch_state(const cmpc_spec *sp, int32_t B, const 
   for (auto &b : emu_wave_barrier) { b.count.store(0); b.gen.store(0); b.width = 64; }
   if (pair) run_batch<4, 1, true>(ka, lds.data());
   else if (sp->nv == 4) run_batch<4, 1>(ka, lds.data());
-  else if (nw8 == 2) run_batch<8, 2>(ka, lds.data());
-  else run_batch<8, 1>(ka, lds.data());
+  else run_batch<8, 2>(ka, lds.data());
   return 0;
 }
 
 extern "C" int cmpc_emu_lds_bytes(int nv) {
-  return (int)(sizeof(double) * ((nv == 4) ? cmpc::Dims<4>::LDS_DOUBLES
-                                 : (cmpc::WAVES_NV8 == 2) ? cmpc::Dims<8, 2>::LDS_DOUBLES : cmpc::Dims<8>::LDS_DOUBLES));
+  return (int)(sizeof(double) * ((nv == 4) ? cmpc::Dims<4>::LDS_DOUBLES : cmpc::Dims<8, 2>::LDS_DOUBLES));
 }

@@ -61,13 +61,11 @@ def test_kernel_source_eight_vertex_patch(emu, oracle):
     assert rel_inf(got, ref).max() < 1e-9
 
 
-@pytest.mark.parametrize("waves", ["1", "2"])
-def test_kernel_source_eight_vertex_one_and_two_waves(emu, oracle, monkeypatch, waves):
-    """The 8-vertex solver as one wave and as the two-wave workgroup the product launches (pivot chains in the first
-    wave, rows 64.. of the stage block in the second, trailing tiles alternating), LDS and slab pre-filled with NaN,
-    two instances so that slab reuse is covered."""
+def test_kernel_source_eight_vertex_two_wave_workgroup(emu, oracle, monkeypatch):
+    """The 8-vertex solver as the two-wave workgroup the product launches (pivot chains in the first wave, rows 64.. of the
+    stage block in the second, trailing tiles alternating; round 5: G'PG out of registers, one column of the 92 per lane
+    of the 128), LDS and slab pre-filled with NaN, two instances so that slab reuse is covered."""
     monkeypatch.setenv("CMPC_EMU_FILL", "nan")
-    monkeypatch.setenv("CMPC_EMU_WAVES", waves)
     spec, rec = wl.make_workload("long_horizon", B=2, N=5)
     cs = oracle_spec(oracle, spec)
     got, st, it, kk = _emu_solve(emu, cs, rec)

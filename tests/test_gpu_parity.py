@@ -104,8 +104,11 @@ KERNELS = {"single": 1, "pair": 2}
 KERNEL_NAMES = {("single", 4): "cmpc_solve_kernel<4, 1>", ("pair", 4): "cmpc_solve_pair_kernel<4, 2>",
                 ("single", 8): "cmpc_solve_kernel<8, 2>"}
 CASES = [("perturbed", 256, 20, 1), ("payload", 512, 20, 1), ("randomized", 512, 20, 1), ("perturbed", 128, 10, 1),
-         ("perturbed", 64, 3, 1), ("perturbed", 32, 40, 1), ("long_horizon", 64, 10, 1), ("long_horizon", 48, 40, 1),
+         ("perturbed", 64, 3, 1), ("perturbed", 32, 40, 1), ("long_horizon", 64, 10, 1), ("long_horizon", 512, 40, 1),
          ("perturbed", 128, 10, 10), ("perturbed", 64, 20, 10)]
+# (the N = 40, 8-vertex case ran 48 instances in rounds 2-4: too few to carry a 10 % share -- the same population gives 3 of 47
+# and 5 of 47 beyond 1e-4 with two kernels whose rate at 512 instances is 5.3 % and 5.7 %; round 5, gpurun_out/r05n -- it
+# runs 512 now, the level is the table's)
 CASES_BY_KERNEL = [c + (k,) for c in CASES for k in (("single",) if c[0] == "long_horizon" else ("single", "pair"))]
 
 
@@ -359,7 +362,7 @@ def test_shipped_queue_order_is_not_worse_than_the_input_order(gpu):
     from cmpc_amd import queue_order as qo
     spec, rec = wl.make_workload("randomized", B=8192)
     _, st, it, _ = _solve(gpu, spec, rec)
-    slots = 256 * 6
+    slots = 256 * 7
 
     def makespan(order):
         h = [0] * slots

@@ -25,7 +25,8 @@ def write(name, table):
 
 for name in ("bench_line.json", "bench_line_perturbed.json", "bench_line_payload.json", "bench_line_long_horizon.json",
              "walk_demo.txt", "parity_report.txt", "full_parity.txt", "selflaunch_2rank.json", "tail_randomized.txt",
-             "tail_long_horizon.txt", "bench_line_seed777.json", "bench_line_perturbed_single_wave.json", "small_batch_latency.txt"):
+             "tail_long_horizon.txt", "bench_line_seed777.json", "bench_line_perturbed_single_wave.json", "small_batch_latency.txt",
+             "phase_randomized.txt", "wg_sweep.txt", "kernel_crossover.txt", "deal_replay.txt", "gpu_tests.log"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))

@@ -18,7 +18,7 @@ SEED = os.environ.get("SEED")
 spec, rec = wl.make_workload(WL, B=B, N=int(N) if N else None, seed=int(SEED) if SEED else None)
 if spec.N > 20:
     spec.max_iter = 150
-slots = min(B, 256 * int(os.environ.get("SLOTS_PER_CU", 6 if spec.nv == 4 else 2)))
+slots = min(B, 256 * int(os.environ.get("SLOTS_PER_CU", 7 if spec.nv == 4 else 2)))
 pred = qo.predicted_iterations(rec, spec)
 order = np.argsort(-qo.bucket_of(pred), kind="stable")
 

@@ -12,7 +12,7 @@ from oracle import oracle_lib as ol
 from conftest import oracle_spec, rel_inf
 
 CASES = [("perturbed", 256, 20, 1), ("payload", 512, 20, 1), ("randomized", 512, 20, 1), ("perturbed", 128, 10, 1),
-         ("perturbed", 64, 3, 1), ("perturbed", 32, 40, 1), ("long_horizon", 64, 10, 1), ("long_horizon", 48, 40, 1),
+         ("perturbed", 64, 3, 1), ("perturbed", 32, 40, 1), ("long_horizon", 64, 10, 1), ("long_horizon", 512, 40, 1),
          ("perturbed", 128, 10, 10), ("perturbed", 64, 20, 10)]
 if len(sys.argv) > 1:
     CASES = [c for c in CASES if f"{c[0]}-{c[1]}-{c[2]}-{c[3]}" in sys.argv[1:]]

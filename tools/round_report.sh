@@ -25,3 +25,12 @@ python tools/walk_demo.py > "$out/walk_demo.txt" 2>&1; tail -2 "$out/walk_demo.t
 python tools/parity_report.py > "$out/parity_report.txt" 2>&1; echo "parity report done"
 for w in "randomized 8192" "payload 4096" "perturbed 4096"; do python tools/full_parity.py $w; done > "$out/full_parity.txt" 2>&1; tail -4 "$out/full_parity.txt"
 CMPC_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 2 --warmup 1 --no-extras --no-cpu-baseline > "$out/selflaunch_2rank.json" 2> "$out/selflaunch_2rank.err"; echo "self-launch rc $?"
+# round 5: phase profile, residency sweep (developer build: CMPC_WG_PER_CU), kernel crossover, the deal over eight ranks replayed
+python tools/phase_profile.py randomized 8192 2>&1 | grep -v amdgpu.ids > "$out/phase_randomized.txt"
+bash tools/wg_sweep.sh tools/libcmpc_amd_dev.so 1 7 > "$out/wg_sweep.txt" 2>&1
+python tools/kernel_crossover.py randomized 2048 3072 4096 5120 8192 2>&1 | grep -v amdgpu.ids > "$out/kernel_crossover.txt"
+python tools/kernel_crossover.py payload 2048 3072 4096 5120 2>&1 | grep -v amdgpu.ids >> "$out/kernel_crossover.txt"
+python tools/deal_replay.py randomized 8 2>&1 | grep -v amdgpu.ids > "$out/deal_replay.txt"
+python tools/deal_replay.py --sorted randomized 8 2>&1 | grep -v amdgpu.ids >> "$out/deal_replay.txt"
+python tools/deal_replay.py long_horizon 8 2>&1 | grep -v amdgpu.ids >> "$out/deal_replay.txt"
+echo "round-5 extras done"

@@ -25,7 +25,7 @@ N = spec.N
 fl = np.stack([rec[:, 24 + 19 * np.arange(N) + 17], rec[:, 24 + 19 * np.arange(N) + 18]], -1)
 fl = np.concatenate([fl, rec[:, None, 22:24]], 1)
 sw = (np.diff(fl, axis=0 if fl.ndim == 1 else 1) != 0).any(axis=(1, 2))
-slots = min(B, 256 * int(os.environ.get("SLOTS_PER_CU", 6 if spec.nv == 4 else 2)))   # resident workgroups (cmpc_hip.hip)
+slots = min(B, 256 * int(os.environ.get("SLOTS_PER_CU", 7 if spec.nv == 4 else 2)))   # resident workgroups (cmpc_hip.hip)
 
 
 def makespan(order):
