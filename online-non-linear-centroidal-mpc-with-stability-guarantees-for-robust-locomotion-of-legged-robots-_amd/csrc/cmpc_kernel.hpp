@@ -950,7 +950,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     for (int f = 0; f < 2; ++f) {
       constexpr int FC = 3 * NV;                // force columns of one foot
       double alf[(NV == 4) ? 14 : 28], dvv[(NV == 4) ? 14 : 28];   // Lyapunov gradient and R'v_j of the foot's columns, one batch each
-      if constexpr (NV == 4) { lds_read_strided14<1>(alf, al + f * FC); lds_read_strided14<1>(dvv, &L(D::oVDV + f * FC)); }
+      if constexpr (NV == 4) lds_read_pair14(alf, dvv, al + f * FC, &L(D::oVDV + f * FC));     // (one wait for both)
       else { lds_read_strided28<1>(alf, al + f * FC); lds_read_strided28<1>(dvv, &L(D::oVDV + f * FC)); }
       const double cf0 = cst[f][0], cf1 = cst[f][1], cf2 = cst[f][2];
       const double gmf = gm[f];
@@ -982,9 +982,9 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     const bool hwc_row = (k == 1) && is_state && s >= 6 && s < 9;
     const double hwc_c = hwc_row ? 4 * sig[R_HWC] * x[(s >= 6 && s < 9) ? s : 6] : 0.0;
     double als[14];                             // al / x of the 12 leading state columns (c, v, hw, theta)
-    lds_read_strided14<1>(als, al + NU);
     double olds[14];
-    if constexpr (RMW) lds_read_strided14<1>(olds, row + NU);
+    if constexpr (RMW) lds_read_pair14(als, olds, al + NU, row + NU);      // (one wait for both)
+    else lds_read_strided14<1>(als, al + NU);
 #pragma unroll
     for (int sj = 0; sj < 12; ++sj) {
       const int j = NU + sj;
@@ -1545,23 +1545,24 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       const double *bv = &L(D::oBV);
       double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
       if constexpr (D::P_PACKED) {
-        // row `lane` of the packed triangle: columns <= lane contiguous in the row, the others down column `lane`
-        static_assert(!D::P_PACKED || NXA == 28, "three batches of ten");
-        double pr[30];
+        // row `lane` of the packed triangle = its column `lane`: word (q, lane) at max(tri(lane), lane + tri(q - 1)) + q
+        // (gt_phase), two batches of fourteen
+        static_assert(!D::P_PACKED || NXA == 28, "two batches of fourteen");
+        double pr[28];
         {
-          const int tl = tri(lane);
+          const cmpc_lds_word wt = cmpc_lds_word_at(&R(D::oP), tri(lane)), wc = cmpc_lds_word_at(&R(D::oP), lane);
 #pragma unroll
-          for (int q0 = 0; q0 < 30; q0 += 10) {
-            cmpc_lds_word pa[10];
-            double v[10];
+          for (int q0 = 0; q0 < NXA; q0 += 14) {
+            cmpc_lds_word pa[14];
+            double v[14];
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {
-              const int qq = (q0 + q < NXA) ? q0 + q : NXA - 1;          // (the last batch repeats column 27 twice)
-              pa[q] = cmpc_lds_word_at(&R(D::oP), (qq <= lane) ? tl + qq : tri(qq) + lane);
+            for (int q = 0; q < 14; ++q) {
+              const cmpc_lds_word alt = wc + CMPC_LDS_WORDS(tri(q0 + q - 1));
+              pa[q] = (wt > alt) ? wt : alt;
             }
-            lds_read_gather10(v, pa);
+            if (q0 == 0) lds_read_gather_off14<0>(v, pa); else lds_read_gather_off14<14>(v, pa);
 #pragma unroll
-            for (int q = 0; q < 10; ++q) pr[q0 + q] = v[q];
+            for (int q = 0; q < 14; ++q) pr[q0 + q] = v[q];
           }
         }
 #pragma unroll
