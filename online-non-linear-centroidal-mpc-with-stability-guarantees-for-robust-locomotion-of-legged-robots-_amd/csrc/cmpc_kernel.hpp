@@ -1132,15 +1132,20 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         const int c = lr[0][n];
         // word (q, c) of the packed triangle = P + max(tri(c), c + tri(q - 1)) + q
         const cmpc_lds_word wt = cmpc_lds_word_at(Pp, tri(c)), wc = cmpc_lds_word_at(Pp, c);
+        if (n >= 1 && n <= 3) {
+          // the three dense rows: the same column 6, 7, 8 of P in every lane -- uniform addresses, all of them immediates,
+          // the whole column under one wait
+          double v[28];
+          if (n == 1) lds_read_pcol_all<6>(v, Pp); else if (n == 2) lds_read_pcol_all<7>(v, Pp); else lds_read_pcol_all<8>(v, Pp);
+#pragma unroll
+          for (int q = 0; q < 28; ++q) { tc[q] = CMPC_FMA(g, v[q], tc[q]); CMPC_OPAQUE_D(tc[q]); }
+          CMPC_SCHED_FENCE();
+          continue;
+        }
 #pragma unroll
         for (int q0 = 0; q0 < NXA; q0 += 14) {
           double v[14];
-          if (n >= 1 && n <= 3) {
-            // the three dense rows: the same column 6, 7, 8 of P in every lane -- uniform addresses, all of them immediates
-            if (n == 1) { if (q0 == 0) lds_read_pcol14<6, 0>(v, Pp); else lds_read_pcol14<6, 14>(v, Pp); }
-            else if (n == 2) { if (q0 == 0) lds_read_pcol14<7, 0>(v, Pp); else lds_read_pcol14<7, 14>(v, Pp); }
-            else { if (q0 == 0) lds_read_pcol14<8, 0>(v, Pp); else lds_read_pcol14<8, 14>(v, Pp); }
-          } else {
+          {
             cmpc_lds_word a[14];
 #pragma unroll
             for (int q = 0; q < 14; ++q) {
@@ -1778,26 +1783,28 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       // P_k b_{k-1} for the stage the Riccati wave is working on: P_k from this image's packed M (rows NU + i hold
       // [Ls row i | P_k row i up to the diagonal]; the same words the single wave reads from its P copy), b from the other
       // image, where stage k - 1 was evaluated; the product is left in that image's XN1 for this wave's next step.
-      static_assert(!PIPE || (D::P_PACKED && NXA == 28), "three batches of ten");
+      static_assert(!PIPE || (D::P_PACKED && NXA == 28), "two batches of fourteen");
       double *other = ldsR + ((k - 1) & 1) * D::LDS_DOUBLES;
       if (lane < NXA) {
         const double *bv = other + D::oBV;
         double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-        double pr[30];
+        double pr[28];
         {
-          const int tl = tri(NU + lane) + NU;
+          // word (q, lane) of P_k inside the packed image: row NU + max(q, lane), column NU + min(q, lane), i.e.
+          // max(f(lane) + q, f(q) + lane) with f(i) = tri(NU + i) + NU -- the max-address form of gt_phase, two batches
+          const cmpc_lds_word wt = cmpc_lds_word_at(&L(D::oM), tri(NU + lane) + NU), wc = cmpc_lds_word_at(&L(D::oM), lane);
 #pragma unroll
-          for (int q0 = 0; q0 < 30; q0 += 10) {
-            cmpc_lds_word pa[10];
-            double v[10];
+          for (int q0 = 0; q0 < NXA; q0 += 14) {
+            cmpc_lds_word pa[14];
+            double v[14];
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {
-              const int qq = (q0 + q < NXA) ? q0 + q : NXA - 1;
-              pa[q] = cmpc_lds_word_at(&L(D::oM), (qq <= lane) ? tl + qq : tri(NU + qq) + NU + lane);
+            for (int q = 0; q < 14; ++q) {
+              const cmpc_lds_word alt = wc + CMPC_LDS_WORDS(tri(NU + q0 + q) + NU - (q0 + q));
+              pa[q] = (wt > alt) ? wt : alt;
             }
-            lds_read_gather10(v, pa);
+            if (q0 == 0) lds_read_gather_off14<0>(v, pa); else lds_read_gather_off14<14>(v, pa);
 #pragma unroll
-            for (int q = 0; q < 10; ++q) pr[q0 + q] = v[q];
+            for (int q = 0; q < 14; ++q) pr[q0 + q] = v[q];
           }
         }
 #pragma unroll
