@@ -435,6 +435,7 @@ int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, cons
   ka.status = status; ka.iters = iters; ka.kkt = kkt_res;
   ka.scratch = h->scratch; ka.scratch_stride = h->slab_doubles;
   ka.prof = h->prof;
+  cmpc::fill_levels(ka);
   const int grid = B < h->grid ? B : h->grid;
   if (B > h->order_cap) {                       // grows rarely; hipFree / hipMalloc synchronise the device
     if (h->order) (void)hipFree(h->order);

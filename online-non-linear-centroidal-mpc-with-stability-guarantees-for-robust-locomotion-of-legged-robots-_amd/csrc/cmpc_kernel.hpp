@@ -62,6 +62,31 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 #define CMPC_OPAQUE_D(x) asm volatile("" : "+v"(x))
 // a wave-uniform integer the compiler cannot prove uniform: said so, it lives in a scalar register
 #define CMPC_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
+// a wave-uniform number of the problem spec (a kernel argument, in scalar registers), opaque at every use: what the
+// optimiser can derive from the spec alone (2 w, w / 2, 1 - k1^2, ... -- some twenty products) it computes at kernel entry
+// and keeps in VECTOR registers through the whole solve (there is no scalar fp64 arithmetic), forty-five of them
+static __device__ __forceinline__ double cmpc_fresh(double a) { asm volatile("" : "+s"(a)); return a; }
+#ifdef CMPC_FRESH_SPEC
+#define SPD(field) cmpc_fresh(sp.field)
+#else
+#define SPD(field) (sp.field)
+#endif
+// a double every lane holds the same value of, said so: it lives in a scalar register pair (spilled, that is two
+// v_readlane; a vector register spilled is a scratch load whose wait also drains every global load in flight)
+static __device__ __forceinline__ double cmpc_uniform_d(double v) {
+  union { double d; int i[2]; } u; u.d = v;
+  int lo, hi;   // (spelled out: the builtin is folded away where the optimiser can see that the value is uniform -- and the value stays where the vector ALU put it)
+  // gfx950 wants a wait state between a vector-ALU write of a register and a v_readfirstlane of it, and two between the
+  // scalar result and a vector-ALU read of it; the compiler pads the instructions it issues itself, not the text of an asm
+  asm("s_nop 0\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 1" : "=s"(lo), "=s"(hi) : "v"(u.i[0]), "v"(u.i[1]));
+  u.i[0] = lo; u.i[1] = hi;
+  return u.d;
+}
+#ifdef CMPC_NO_UNIFORM_D
+#define CMPC_UNIFORM_D(x) (x)
+#else
+#define CMPC_UNIFORM_D(x) cmpc_uniform_d(x)
+#endif
 // nothing is scheduled across this point (keeps a batch of loads, its wait and its arithmetic together: left to itself
 // the scheduler parks the loaded words and spills them)
 #define CMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -81,6 +106,8 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 #endif
 #ifndef CMPC_RELANE
 #define CMPC_RELANE(x) do { } while (0)
+#define SPD(field) (sp.field)
+#define CMPC_UNIFORM_D(x) (x)
 #endif
 // x * y + z in ONE rounding, spelled out.  Everywhere else the multiply-adds are formed by the compiler's contraction of
 // a * b + c, whose choices depend on the code around (which product is hoisted out of a masked block, which sum is
@@ -121,6 +148,9 @@ struct KArgs {
   double *scratch;      // [grid][scratch_stride]
   size_t scratch_stride;
   long long *prof;      // [8] phase cycle sums (CMPC_PROFILE builds), else null
+  // levels of the outer loop derived from sp.tol (cmpc::fill_levels, on the host): as kernel arguments they sit in scalar
+  // registers; computed in the kernel they are vector-ALU results hoisted to kernel entry -- and spilled
+  double tol_acc, tol_tenth;
 };
 
 enum { R_LYAP = 0, R_CZ = 1, R_HWC = 2, R_BOX = 3, R_FRIC = 15 };
@@ -128,6 +158,7 @@ enum { R_LYAP = 0, R_CZ = 1, R_HWC = 2, R_BOX = 3, R_FRIC = 15 };
 // termination safeguards (same constants as the oracle)
 constexpr double ACC_FACTOR = 100.0;
 constexpr int ACC_ITERS = 8;
+inline void fill_levels(KArgs &ka) { ka.tol_acc = ACC_FACTOR * ka.sp.tol; ka.tol_tenth = ka.sp.tol / 10; }
 constexpr double STALL_STEP = 1e-7;
 constexpr int STALL_ITERS = 6;
 // no progress at a barrier value: NOPROG_ITERS iterations without halving the best error of that barrier problem
@@ -465,7 +496,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   CMPC_DEV double gam_k(int k, int f) const { return (k == N) ? L(D::oHDR + 22 + f) : L(D::oSR + 17 + f); }
   CMPC_DEV double gam_km1(int f) const { return L(D::oSRP + 17 + f); }
   CMPC_DEV void vert_local(int j, double &vx, double &vy) const {
-    const double Lh = sp.foot_length * 0.5, Wh = sp.foot_width * 0.5;
+    const double Lh = SPD(foot_length) * 0.5, Wh = SPD(foot_width) * 0.5;
     const double cx[8] = {Lh, Lh, -Lh, -Lh, Lh, 0.0, -Lh, 0.0};
     const double cy[8] = {Wh, -Wh, -Wh, Wh, 0.0, -Wh, 0.0, Wh};
     vx = cx[j]; vy = cy[j];
@@ -520,7 +551,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   //       [32..34] z1, [35..37] z2, [38..40] un, [41..43] gz1, [44..46] gz2, [47..49] V, [50] lyap val
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void stage_geometry(int k) {
-    const double d = sp.delta, m = L(D::oHDR + 20);
+    const double d = SPD(delta), m = L(D::oHDR + 20);
     // (A) one lane per contact vertex: rotated offsets, lever arm, and the vertex's terms of every
     // per-foot sum (torque r x f, yaw term (R'v) x f, yaw-yaw curvature) -- products staged in the
     // H0/H1 block (written later in the sweep), summed in (B) by one lane per result.
@@ -619,9 +650,9 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       const double xnext = L(D::oXN1 + q);
       const double gsel = (q >= 16) ? g18 : g17;
       const double xn = (q < 3) ? own + d * x3a
-                      : (q < 6) ? own + d * (((a == 2) ? -sp.g : 0.0) + (g17 * m_a + g18 * m_3a) / m)
+                      : (q < 6) ? own + d * (((a == 2) ? -SPD(g) : 0.0) + (g17 * m_a + g18 * m_3a) / m)
                       : (q < 9) ? own + d * m_tau
-                      : (q < 12) ? own + d / m * (sp.k1 * (xa - sra) + x3a - sr3a)
+                      : (q < 12) ? own + d / m * (SPD(k1) * (xa - sra) + x3a - sr3a)
                       : (q < CMPC_NX) ? own + d * (1 - gsel) * ua : ua;
       if (lane < NXA) L(D::oBV + q) = xn - xnext;
     }
@@ -634,7 +665,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     for (int h = 0; h < NH; ++h) column_list(lane + WS * h, lr[h], lg[h], gh, gl, gr, m);
   }
   CMPC_DEV void column_list(const int col, int *r, double *g, const double *gh, double gl, double gr, double m) const {
-    const double d = sp.delta;
+    const double d = SPD(delta);
     {
 #pragma unroll
       for (int n = 0; n < 6; ++n) { r[n] = 0; g[n] = 0.0; }
@@ -654,7 +685,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       } else {
         const int s = col - NU;
         if (s < CMPC_NX) { r[0] = s; g[0] = 1.0; }
-        if (s < 3) { r[4] = 9 + s; g[4] = d * sp.k1 / m; }
+        if (s < 3) { r[4] = 9 + s; g[4] = d * SPD(k1) / m; }
         else if (s < 6) { r[4] = s - 3; g[4] = d; r[5] = 9 + s - 3; g[5] = d / m; }
       }
     }
@@ -664,12 +695,12 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   // Inequality rows g (<= 0), Lyapunov gradient AL, activity.  reference :193-271
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void stage_ineq(int k, double x0n2) {
-    const double m = L(D::oHDR + 20), muf = L(D::oHDR + 21), rl = sp.relax;
-    const double d = sp.delta, k1 = sp.k1, k2 = sp.k2;
+    const double m = L(D::oHDR + 20), muf = L(D::oHDR + 21), rl = SPD(relax);
+    const double d = SPD(delta), k1 = SPD(k1), k2 = SPD(k2);
     if (k < N && lane < 3) {
       const int a = lane;
       const double *x = &L(D::oXK), *sr = &L(D::oSR);
-      const double grav = (a == 2) ? -sp.g : 0.0;
+      const double grav = (a == 2) ? -SPD(g) : 0.0;
       const double V = (sr[17] * L(D::oMISC + a) + sr[18] * L(D::oMISC + 3 + a)) / m;
       const double z1 = x[a] + d * x[3 + a] - sr[a];
       const double z2 = k1 * z1 + x[3 + a] + d * (grav + V) - sr[3 + a];
@@ -716,12 +747,12 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         const double gs = L(D::oSR + 17 + f), gN = L(D::oHDR + 22 + f);
         const double fx = L(D::oUK + 3 * v), fy = L(D::oUK + 3 * v + 1), fz = L(D::oUK + 3 * v + 2);
         const double gk = (k == N) ? gN : gs;                            // contact flag at node k
-        const double bx = (ab == 0) ? sp.box[0] : (ab == 1) ? sp.box[1] : sp.box[2];
+        const double bx = (ab == 0) ? SPD(box[0]) : (ab == 1) ? SPD(box[1]) : SPD(box[2]);
         const double g_box = ((qb & 1) ? -1.0 : 1.0) * ((xa - pa) * gk) - bx - rl;
         const double e = (t == 0) ? fx - muf * fz : (t == 1) ? -fx - muf * fz : (t == 2) ? fy - muf * fz
                        : (t == 3) ? -fy - muf * fz : -fz;
         const double g_fr = gs * e - rl;
-        const double g_sel = (rc == R_LYAP) ? red - rl : (rc == R_CZ) ? x2 - sp.cz_max - rl
+        const double g_sel = (rc == R_LYAP) ? red - rl : (rc == R_CZ) ? x2 - SPD(cz_max) - rl
                            : (rc == R_HWC) ? x6 * x6 + x7 * x7 + x8 * x8 - hw0n2 - rl : (is_box ? g_box : g_fr);
         const bool act = (rc == R_LYAP) ? (k < N) : (rc == R_CZ) ? (k >= 1 && k < N) : (rc == R_HWC) ? (k == 1)
                        : (is_box ? (k >= 1 && gk != 0.0) : (k < N && gs != 0.0));
@@ -797,19 +828,19 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     double v = 0.0;
     if (is_u) {
       if (stage) {
-        v = sp.prox * (u_ - upx);
+        v = SPD(prox) * (u_ - upx);
         if (is_f) {
           const double a_ = g1 * g1 / NV, coef = NV * a_ * a_ - 2 * a_;
-          const double wa = sp.w_force * g1, wb = sp.w_force * (1 - g1);
+          const double wa = SPD(w_force) * g1, wb = SPD(w_force) * (1 - g1);
           v += wa * (2 * coef * fsum + 2 * u_) + wb * 2 * u_;
-          if (a == 2 && k >= 1) v += 2 * sp.w_rate * gm1 * (u_ - x_);
+          if (a == 2 && k >= 1) v += 2 * SPD(w_rate) * gm1 * (u_ - x_);
         }
       }
     } else if (k >= 1) {
-      const double wpos = (s < 3) ? 2 * ((s == 2) ? wz : sp.w_cxy) : ((is_yaw || is_pos) ? 2 * sp.w_foot * gk * gk : 0.0);
+      const double wpos = (s < 3) ? 2 * ((s == 2) ? wz : SPD(w_cxy)) : ((is_yaw || is_pos) ? 2 * SPD(w_foot) * gk * gk : 0.0);
       v = wpos * (x_ - pr);
-      if (s >= 6 && s < 9) v = stage ? 2 * sp.w_hw * x_ : 0.0;
-      if (is_fp) v = stage ? -2 * sp.w_rate * gm1 * (u_ - x_) : 0.0;
+      if (s >= 6 && s < 9) v = stage ? 2 * SPD(w_hw) * x_ : 0.0;
+      if (is_fp) v = stage ? -2 * SPD(w_rate) * gm1 * (u_ - x_) : 0.0;
     }
     return v;
   }
@@ -844,7 +875,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     const double *al = &L(D::oAL);
     const bool stage = k < N;
     const double sigL = sig[R_LYAP], zL = stage ? L(D::oZK + R_LYAP) : 0.0;
-    const double d = sp.delta, k1 = sp.k1;
+    const double d = SPD(delta), k1 = SPD(k1);
     const double gam[2] = {L(D::oSR + 17), L(D::oSR + 18)};
     // Lyapunov quadratic-form coefficients hq (4x4 over c, v, theta, V)
     const double a1[4] = {1, d, 0, 0}, a2[4] = {k1, k1 * d + 1, 0, d};
@@ -911,10 +942,10 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     const bool frow = stage && is_force;
     const double g1 = f_i ? gam[1] : gam[0];
     const double a_ = g1 * g1 / NV, coef = NV * a_ * a_ - 2 * a_;
-    const double wa = sp.w_force * g1, wb = sp.w_force * (1 - g1);
+    const double wa = SPD(w_force) * g1, wb = SPD(w_force) * (1 - g1);
     const double g2 = g1 * g1;
     const double mean_c = frow ? 2 * wa * coef : 0.0;
-    const double d_rate = (a_i == 2 && k >= 1) ? 2 * sp.w_rate * (f_i ? gkm1 : gkm0) : 0.0;
+    const double d_rate = (a_i == 2 && k >= 1) ? 2 * SPD(w_rate) * (f_i ? gkm1 : gkm0) : 0.0;
     const double d_fric = (a_i == 0) ? g2 * (s50 + s51) : (a_i == 1) ? g2 * (s52 + s53)
                         : g2 * (muf * muf * (s50 + s51 + s52 + s53) + s54);
     double diag = reg;                          // (terms added one by one, in the order of the branchy form: adding 0.0
@@ -927,7 +958,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     // carried-force rows: rate coupling with the f_z column of the same vertex
     const bool is_fp = is_state && s >= CMPC_NX;
     const int f_fp = is_fp ? (s - CMPC_NX) / NV : 0;
-    const double wr_fp = (is_fp && k >= 1 && stage) ? sp.w_rate * (f_fp ? gkm1 : gkm0) : 0.0;
+    const double wr_fp = (is_fp && k >= 1 && stage) ? SPD(w_rate) * (f_fp ? gkm1 : gkm0) : 0.0;
     const int j_fp = (is_fp && k >= 1 && stage) ? 3 * (s - CMPC_NX) + 2 : -1;
     // words of the diagonal (state rows)
     const int sc = is_state ? s : 0;
@@ -1007,15 +1038,15 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     if (ti >= 0) diag += sA * al_i + (is_force ? hV * g1 : ((ti == 0) ? zq[0] : (ti == 1) ? zq[1] : zq[2]));
     const bool kp = k >= 1;
     const double gk = f_ft ? gk1 : gk0;
-    diag += (kp && s_c) ? 2 * ((s == 2) ? wz : sp.w_cxy) : 0.0;
+    diag += (kp && s_c) ? 2 * ((s == 2) ? wz : SPD(w_cxy)) : 0.0;
     diag += (kp && s_c && s == 2) ? sCZ : 0.0;
-    diag += (kp && s_hw && stage) ? 2 * sp.w_hw : 0.0;
+    diag += (kp && s_hw && stage) ? 2 * SPD(w_hw) : 0.0;
     diag += (kp && s_hw && k == 1) ? 2 * zHW + 4 * sHW * xs * xs : 0.0;
-    diag += (kp && s_yaw) ? 2 * sp.w_foot * gk * gk : 0.0;
-    diag += (kp && s_pos) ? 2 * sp.w_foot * gk * gk + gk * gk * (sb0 + sb1) : 0.0;
+    diag += (kp && s_yaw) ? 2 * SPD(w_foot) * gk * gk : 0.0;
+    diag += (kp && s_pos) ? 2 * SPD(w_foot) * gk * gk + gk * gk * (sb0 + sb1) : 0.0;
     diag += (kp && is_fp && stage) ? 2 * wr_fp : 0.0;
     diag += (ctype == 3) ? q30 : 0.0;
-    diag = is_state ? diag : (stage ? diag + sp.prox : reg + 1.0);   // no inputs at the terminal node
+    diag = is_state ? diag : (stage ? diag + SPD(prox) : reg + 1.0);   // no inputs at the terminal node
     if constexpr (RMW) { CMPC_OPAQUE_D(diag); diag += row[i]; }
     if (live) row[i] = diag;
   }
@@ -1178,9 +1209,9 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     }
     if constexpr (D::GT_FIRST) sync();         // every lane has read its words of P: the region is free for the late vectors
     CMPC_TICK(10);
-    const double d = sp.delta;
+    const double d = SPD(delta);
     const double cf[2] = {d * gl / m, d * gr / m}, cv[2] = {d * (1 - gl), d * (1 - gr)};
-    const double ck = d * sp.k1 / m, cd = d, cdm = d / m;
+    const double ck = d * SPD(k1) / m, cd = d, cdm = d / m;
     gt_groups<RMW>(std::make_integer_sequence<int, GT_FULL>{}, tc, cf, cv, ck, cd, cdm);
     sync();
     CMPC_TICK(14);
@@ -1828,10 +1859,11 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     // height weight of node k, w_z[k-1] = (w/2) e^{-(k-1)} + w/2 (reference :301-305): one exp per sweep, then
     // e^{-(k-1)} by repeated multiplication as k runs down (the library exp is ~1.5 KB of code per use)
     const double e1 = 2.718281828459045235360287;
-    double ez = exp(-(double)(N - 1));
+    double ez = CMPC_UNIFORM_D(exp(-(double)(N - 1)));   // (formed at kernel entry -- it depends on N alone --, kept in scalar registers;
+    CMPC_OPAQUE_D(ez);                                   //  its products with the weight are formed here, not carried from there)
     if constexpr (!PIPE) {
       for (int k = N; k >= 0; --k) {
-        const double wz = sp.w_cz_const * 0.5 * ez + sp.w_cz_const * 0.5;
+        const double wz = SPD(w_cz_const) * 0.5 * ez + SPD(w_cz_const) * 0.5;
         ez *= e1;
         eval_stage(k, mu, reg, wz, x0n2, er, init);
         if (!riccati_stage(k)) return false;
@@ -1850,7 +1882,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         if (wv == 1) {
           const int kv = N - j + 2, k = N - j;
           if (kv >= 0 && kv <= N) { image(kv); pair_vectors(kv); }
-          const double wz = sp.w_cz_const * 0.5 * ez + sp.w_cz_const * 0.5;
+          const double wz = SPD(w_cz_const) * 0.5 * ez + SPD(w_cz_const) * 0.5;
           ez *= e1;
           if (k >= 0) { image(k); eval_stage(k, mu, reg, wz, x0n2, er, init); }
         } else if (j >= 1 && j <= N + 1) {
@@ -1912,9 +1944,12 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       image(0);
       if (wv == 1) { slack_sweep(mu, ap, ad); return; }
     }
-    const double m = rec[20], muf = rec[21];
+    // (what the whole sweep carries and every lane has the same value of: in scalar registers)
+    mu = CMPC_UNIFORM_D(mu); dmu = CMPC_UNIFORM_D(dmu);
+    const double m = CMPC_UNIFORM_D(rec[20]), muf = CMPC_UNIFORM_D(rec[21]);
     constexpr int NIH = (NI + WS - 1) / WS;
-    const double tau = fmax(0.99, 1 - mu);
+    const double tau = CMPC_UNIFORM_D(fmax(0.99, 1 - mu));
+    const double d_m = CMPC_UNIFORM_D(SPD(delta) / m);
     double lap = 1.0, lad = 1.0;
     double *xdu = ldsR + XCH_AT + XCH_DU;
     constexpr bool MERGE = D::W_MERGE;
@@ -1925,56 +1960,94 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     int cur = D::oXK, nxt = D::oXN1;          // dx_k / dx_{k+1} ping-pong
     if (lane < NXA) { L(cur + lane) = 0.0; gdx[lane] = 0.0; }
     sync();
-    for (int k = 0; k <= N; ++k) {
-      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+    // Every global word of stage k is in registers when the stage starts: the sweep is one serial chain over the stages
+    // and a stage's loads (one HBM round trip, ~2 us) stood exposed at its top.  They are issued a stage ahead instead, each
+    // group as soon as the registers it lands in are free: Ls | P_k after the two products, Lambda's column and the five
+    // words the top of a stage needs after the back substitution (no second set of registers, and no copy at the end of
+    // the stage -- a copy is a use, and a use waits for the load).  What a stage needs after its chain is loaded at its top.
+    struct Early { double l0v, l1v, dg, pv0, pv1; };           // needed at the top of the stage: a stage ahead
+    struct Late { double gh[3][NH], al[NH], sv[NIH], zv[NIH], gv[NIH], hw0, hw1, hw2, bq; };   // needed after the chain
+    double wa[NXA], wb[MERGE ? 1 : NXA], lam[NU];
+    auto load_w = [&](int k) {
+      // Ls[c][lane] (lanes < NU) and P_k[c][r] out of the packed image: P_k[c][r] sits in row NU + max(c, r)
       const GArr st = stage(k);
-      const bool hasA = k < N, hasB = k >= 1;
-      // ---- every global load of the stage, before any use
-      double gh[3][NH];
+      if constexpr (MERGE) {
+        const int lc = (lane < NZ) ? lane : 0;           // lane = NU + r for the P role
+        const int rb = tri(lc) + NU;                    // start of the state part of row NU + r
+#pragma unroll
+        for (int c = 0; c < NXA; ++c) wa[c] = st[D::gM + ((lc < NU || NU + c >= lc) ? tri(NU + c) + lc : rb + c)];
+        wb[0] = 0.0;
+      } else {
+        const int la = (lane < NU) ? lane : 0;
+        const int lbc = (lane < NXA) ? lane : 0, rb = tri(NU + lbc) + NU;
+#pragma unroll
+        for (int c = 0; c < NXA; ++c) wa[c] = st[D::gM + tri(NU + c) + la];
+#pragma unroll
+        for (int c = 0; c < NXA; ++c) wb[c] = st[D::gM + ((c >= lbc) ? tri(NU + c) + NU + lbc : rb + c)];
+      }
+    };
+    auto load_lam = [&](int k) {
+      // column la of Lambda: rows j >= la (the words read for j < la belong to other rows and are never used)
+      const GArr st = stage(k);
+      const int la = (lane < NU) ? lane : 0;
+#pragma unroll
+      for (int j = 0; j < NU; ++j) lam[j] = st[D::gM + tri(j) + la];
+    };
+    auto load_early = [&](int k, Early &w) {
+      const GArr st = stage(k);
+      const int lb_ = MERGE ? lane - NU : lane;
+      const int la = (lane < NU) ? lane : 0, lbc = (lb_ >= 0 && lb_ < NXA) ? lb_ : 0;
+      w.l0v = st[D::gL + la]; w.l1v = st[D::gL1 + la]; w.dg = st[D::gM + tri(la) + la];
+      w.pv0 = st[D::gPV + lbc]; w.pv1 = st[D::gPV1 + lbc];
+    };
+    auto load_late = [&](int k, Late &w) {
+      const GArr st = stage(k);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int h = 0; h < NH; ++h) gh[r][h] = st[D::gGH + r * D::GHS + lane + WS * h];
-      // contact flags of the stage (terminal node: header words 22, 23)
-      const double gl = rec[(k < N) ? 24 + 19 * k + 17 : 22], gr = rec[(k < N) ? 24 + 19 * k + 18 : 23];
+        for (int h = 0; h < NH; ++h) w.gh[r][h] = st[D::gGH + r * D::GHS + lane + WS * h];
       // slack / multiplier directions of the stage are formed here too (one pass over the stages less)
-      double al[NH], sv[NIH], zv[NIH], gv[NIH];
-      double hw0 = 0.0, hw1 = 0.0, hw2 = 0.0;
       if constexpr (!PIPE) {
 #pragma unroll
-        for (int h = 0; h < NH; ++h) { const int c = lane + WS * h; al[h] = st[D::gAL + ((c < NZ) ? c : 0)]; }
+        for (int h = 0; h < NH; ++h) { const int c = lane + WS * h; w.al[h] = st[D::gAL + ((c < NZ) ? c : 0)]; }
 #pragma unroll
         for (int h = 0; h < NIH; ++h) {
           const int r = lane + WS * h, rc = (r < NI) ? r : 0;
-          sv[h] = gsl[k * NI + rc]; zv[h] = gz[k * NI + rc]; gv[h] = st[D::gG + rc];
+          w.sv[h] = gsl[k * NI + rc]; w.zv[h] = gz[k * NI + rc]; w.gv[h] = st[D::gG + rc];
         }
-        hw0 = gx[k * NXA + 6]; hw1 = gx[k * NXA + 7]; hw2 = gx[k * NXA + 8];
+        w.hw0 = gx[k * NXA + 6]; w.hw1 = gx[k * NXA + 7]; w.hw2 = gx[k * NXA + 8];
+      } else {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) w.al[h] = 0.0;
+#pragma unroll
+        for (int h = 0; h < NIH; ++h) { w.sv[h] = 0.0; w.zv[h] = 0.0; w.gv[h] = 0.0; }
+        w.hw0 = 0.0; w.hw1 = 0.0; w.hw2 = 0.0;
       }
-      double wa[NXA], wb[MERGE ? 1 : NXA], lam[NU];
-      const int la = isA ? lane : 0;
-      {
-        // Ls[c][lane] (lanes < NU) and P_k[c][r] out of the packed image: P_k[c][r] sits in row NU + max(c, r)
-        if constexpr (MERGE) {
-          const int lc = (lane < NZ) ? lane : 0;           // lane = NU + r for the P role
-          const int rb = tri(lc) + NU;                    // start of the state part of row NU + r
-#pragma unroll
-          for (int c = 0; c < NXA; ++c) wa[c] = st[D::gM + ((lc < NU || NU + c >= lc) ? tri(NU + c) + lc : rb + c)];
-          wb[0] = 0.0;
-        } else {
-          const int lbc = isB ? lb : 0, rb = tri(NU + lbc) + NU;
-#pragma unroll
-          for (int c = 0; c < NXA; ++c) wa[c] = st[D::gM + tri(NU + c) + la];
-#pragma unroll
-          for (int c = 0; c < NXA; ++c) wb[c] = st[D::gM + ((c >= lbc) ? tri(NU + c) + NU + lbc : rb + c)];
-        }
-      }
-      const double l0v = st[D::gL + la], l1v = st[D::gL1 + la], dg = st[D::gM + tri(la) + la];
-      const int lbc = isB ? lb : 0;
-      const double pv0 = st[D::gPV + lbc], pv1 = st[D::gPV1 + lbc];
-      const double bq = st[D::gB + ((lane < NXA) ? lane : 0)];
-      // column la of Lambda: rows j >= la (the words read for j < la belong to other rows and are never used)
-#pragma unroll
-      for (int j = 0; j < NU; ++j) lam[j] = st[D::gM + tri(j) + la];
+      w.bq = st[D::gB + ((lane < NXA) ? lane : 0)];
+    };
+#ifndef CMPC_FWD_AHEAD_MASK
+#define CMPC_FWD_AHEAD_MASK 7
+#endif
+    constexpr bool AHEAD = ((CMPC_FWD_AHEAD_MASK) >> (PIPE ? 1 : (NW == 1 ? 0 : 2))) & 1;
+    Early sm;
+    // (in the order the loop issues them, and kept so: the waits inside the loop are computed for the worse of the two ways
+    // into it, and vmcnt counts in issue order -- with Ls | P_0 issued last here, every stage waited for Lambda's column
+    // before its first product)
+    if constexpr (AHEAD) { load_w(0); CMPC_SCHED_FENCE(); load_early(0, sm); CMPC_SCHED_FENCE(); load_lam(0); CMPC_SCHED_FENCE(); }
+    else { sm.l0v = 0.0; sm.l1v = 0.0; sm.dg = 0.0; sm.pv0 = 0.0; sm.pv1 = 0.0; }
+    for (int k = 0; k <= N; ++k) {
+      CMPC_RELANE(lane); CMPC_OPAQUE(lane);
+      const bool hasA = k < N, hasB = k >= 1;
+      const int kn = hasA ? k + 1 : k;         // the node whose factors are loaded during this one (terminal node: its own again)
+      // contact flags of the stage (terminal node: header words 22, 23)
+      const double gl = rec[(k < N) ? 24 + 19 * k + 17 : 22], gr = rec[(k < N) ? 24 + 19 * k + 18 : 23];
+      Late lt;
+      load_late(k, lt);
+      if constexpr (!AHEAD) { load_w(k); load_early(k, sm); load_lam(k); }
+      const double (&gh)[3][NH] = lt.gh;
+      const double (&al)[NH] = lt.al, (&sv)[NIH] = lt.sv, (&zv)[NIH] = lt.zv, (&gv)[NIH] = lt.gv;
+      const double hw0 = lt.hw0, hw1 = lt.hw1, hw2 = lt.hw2, bq = lt.bq;
+      const double l0v = sm.l0v, l1v = sm.l1v, dg = sm.dg, pv0 = sm.pv0, pv1 = sm.pv1;
       CMPC_TICK(16);
       // ---- Ls' dx (lanes < NU) and P dx (the other role)
       double accA, accB;
@@ -1985,7 +2058,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
 #pragma unroll
         for (int c = 0; c < NXA; c += 4) {
           a0 += wa[c] * dxv[c]; a1 += wa[c + 1] * dxv[c + 1]; a2 += wa[c + 2] * dxv[c + 2]; a3 += wa[c + 3] * dxv[c + 3];
-        }
+          if (c % 8 == 4) CMPC_SCHED_FENCE();  // (dx eight words at a time: read in one batch it takes 56 registers beside the
+        }                                      //  120 of the factors)
         accA = (a0 + a1) + (a2 + a3);
         if constexpr (!MERGE) {
           double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
@@ -1996,6 +2070,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
           accB = (b0 + b1) + (b2 + b3);
         } else accB = accA;
       }
+      CMPC_OPAQUE_D(accA); CMPC_OPAQUE_D(accB);   // (formed HERE: left alone the two sums sink to their use, below the loads)
+      if constexpr (AHEAD) load_w(kn);         // (the registers of Ls | P_k are free)
       if (hasB && isB) glamn[k * NXA + lb] = pv0 + dmu * pv1 + accB;
       auto slack_dirs = [&](double ldot) {     // ds, dz and the fraction-to-the-boundary bounds of stage k
 #pragma unroll
@@ -2014,20 +2090,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
           }
         }
       };
-      if (!hasA) {                             // terminal node: no inputs; Lyapunov row inactive
-        if constexpr (PIPE) { CMPC_SYNC_WG(); break; }      // (dx_N is in LDS: the slack wave's last stage)
-        double part = 0.0;
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          const int c = lane + WS * h;
-          if (c >= NU && c < NZ) part += al[h] * L(cur + c - NU);
-        }
-        slack_dirs(red_sum(part));
-        sync();                           // the caller reuses the stage vectors
-        break;
-      }
       double duv = 0.0;
-      if (first_wave()) {                      // L' du = -(l + Ls' dx), multipliers by readlane
+      if (hasA && first_wave()) {              // L' du = -(l + Ls' dx), multipliers by readlane (the terminal node has no inputs)
         double treg = isA ? -(l0v + dmu * l1v + accA) : 0.0;
         const double dinv = 1.0 / dg;
 #pragma unroll
@@ -2038,6 +2102,23 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         duv = treg * dinv;
         if (isA) { gdu[k * NU + lane] = duv; L(D::oUK + lane) = duv; }
         if constexpr (PIPE) { if (isA) xdu[(k & 1) * NU + lane] = duv; }
+      }
+      // Every word of `sm` and Lambda's column have had their last use.  EVERY way round the loop passes these loads, the
+      // terminal node's too (whose "break" below runs through the loop's latch as far as the compiler's wait-count analysis
+      // can tell: with the loads behind a branch, Ls | P_k looked freshly issued at the top of a stage, and the wait for it
+      // drained Lambda's column -- vmcnt counts in issue order).
+      if constexpr (AHEAD) { load_early(kn, sm); load_lam(kn); }
+      if (!hasA) {                             // terminal node: Lyapunov row inactive
+        if constexpr (PIPE) { CMPC_SYNC_WG(); break; }      // (dx_N is in LDS: the slack wave's last stage)
+        double part = 0.0;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const int c = lane + WS * h;
+          if (c >= NU && c < NZ) part += al[h] * L(cur + c - NU);
+        }
+        slack_dirs(red_sum(part));
+        sync();                           // the caller reuses the stage vectors
+        break;
       }
       if constexpr (PIPE) CMPC_SYNC_WG();      // du_k and dx_k stand in LDS; the slack wave is done with stage k - 1
       // dense rows: s_r = sum_c GH[r][c] z_c, z = (du, dx), one column per lane
@@ -2072,7 +2153,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         // then the row picks its expression: as an if / else-if chain over the row this was nine divergent paths with an
         // exposed LDS round trip each (round 4; same expressions, same bits)
         const int q = (lane < NXA) ? lane : 0;
-        const double d = sp.delta;
+        const double d = SPD(delta);
         const double *dx = &L(cur), *du = &L(D::oUK);
         const int ia = (q < 3) ? 3 + q : ((q >= 9 && q < 12) ? q - 9 : 0), ib = (q >= 9 && q < 12) ? q - 6 : 0;
         const int ja = (q >= CMPC_NX) ? 3 * (q - CMPC_NX) + 2 : (q == 12) ? 6 * NV + 6 : (q >= 13 && q < 16) ? 6 * NV + q - 13
@@ -2084,8 +2165,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         for (int v = 0; v < NF; ++v) fs += ((v < NV) ? gl : gr) * du[3 * v + ax];
         const double gsel = (q >= 16) ? gr : gl;
         const double ssel = (q == 6) ? s0 : (q == 7) ? s1 : s2;
-        const double inc = (q < 3) ? own + d * xa : (q < 6) ? own + d / m * fs : (q < 9) ? own + ssel
-                         : (q < 12) ? own + d / m * (sp.k1 * xa + xb) : (q < CMPC_NX) ? own + d * (1 - gsel) * ua : ua;
+        const double inc = (q < 3) ? own + d * xa : (q < 6) ? own + d_m * fs : (q < 9) ? own + ssel
+                         : (q < 12) ? own + d_m * (SPD(k1) * xa + xb) : (q < CMPC_NX) ? own + d * (1 - gsel) * ua : ua;
         const double a = bq + inc;
         if (lane < NXA) {
           gdx[(k + 1) * NXA + q] = a;
@@ -2109,9 +2190,10 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   // chain wave (see vector_sweeps).  The stage's own data (slacks, multipliers, row values, Lyapunov gradient) are
   // loaded before the barrier that releases du_k.
   CMPC_DEV void slack_sweep(double mu, double &ap, double &ad) {
-    const double muf = rec[21];
+    mu = CMPC_UNIFORM_D(mu);
+    const double muf = CMPC_UNIFORM_D(rec[21]);
     constexpr int NIH = (NI + WS - 1) / WS;
-    const double tau = fmax(0.99, 1 - mu);
+    const double tau = CMPC_UNIFORM_D(fmax(0.99, 1 - mu));
     double lap = 1.0, lad = 1.0;
     double *xch = ldsR + XCH_AT;
     gsync();                                  // this wave's stores of the evaluation and of the last step
@@ -2273,7 +2355,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       if (has_warm) { v = warm[CMPC_NX * (N + 1) + ks * NU + i]; }
       else if (i < 6 * NV && (i % 3) == 2) {
         const double gl = rec[24 + 19 * k + 17], gr = rec[24 + 19 * k + 18];
-        v = m * sp.g / (NV * (gl + gr)) * (((i / 3) < NV) ? gl : gr);
+        v = m * SPD(g) / (NV * (gl + gr)) * (((i / 3) < NV) ? gl : gr);
       }
       gu[e] = v; gupx[e] = up;
     }
@@ -2330,6 +2412,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   CMPC_DEV void solve(const double *warm, const double *state_in, double *state_out, double *out, int32_t *status,
                       int32_t *iters, double *kkt_out) {
     const double tol = sp.tol;
+    // (what the outer loop compares with, every lane the same value: scalar registers)
+    const double tol_acc = ka.tol_acc, tol_10 = ka.tol_tenth;   // ACC_FACTOR * tol, tol / 10
     const double x0n2 = 0.0;                    // |hw_0|^2 is read from the record header in LDS where it is used
     // closed-loop ticks: resume from the previous tick's central-path point (see the oracle, MU_WARM)
     bool resume = false;
@@ -2353,7 +2437,9 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     // cold state -- every lane reads before any lane writes --, written back before the vector sweeps.
     constexpr bool CNT_LDS = (NW == 1);
     int n_acc = 0, n_stall = 0, polish = -1, since_best = 0;
-    bool use_saved = false;
+    // ("the answer is the saved iterate, already written" rides in the verdict -- bit SAVED of `st` -- until the loop is left:
+    // as a flag of its own it was one more vector register carried across the whole iteration, and the one spilled)
+    constexpr int SAVED = 256;
     // cold scalars of the outer loop live in LDS (every lane reads the same word; written by every lane with the
     // same value, fenced by the phases in between)
     double &reg_last = R(D::oCOLD + 0), &kkt_best = R(D::oCOLD + 1), &kkt_saved = R(D::oCOLD + 2);
@@ -2370,7 +2456,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     // pair through the whole solve and was spilled)
     auto acc_raw = [&]() { double a = sp.acc_tol; CMPC_OPAQUE_D(a); return a; };
     auto acc_tol = [&]() { return fmax(acc_raw(), tol); };
-    auto save_tol = [&]() { return fmax(fmax(acc_raw(), tol), ACC_FACTOR * tol); };
+    auto save_tol = [&]() { return fmax(fmax(acc_raw(), tol), tol_acc); };
     // (the pair: phases that walk the horizon serially belong to wave 0; the other wave waits at the next barrier)
     if (!PIPE || wv == 0) initial_point(resume ? state_in : warm, warm, resume);
     pair_sync();
@@ -2414,10 +2500,10 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         n_acc = (int)R(D::oCOLD + 4); since_best = (int)R(D::oCOLD + 5); polish = (int)R(D::oCOLD + 6); n_stall = (int)R(D::oCOLD + 7);
       }
       if constexpr (PIPE) { CMPC_SYNC_WG(); } else sync();
-      if (polish >= 0 && kkt > ACC_FACTOR * tol) {
+      if (polish >= 0 && kkt > tol_acc) {
         // polishing lost ground (the step at the final barrier value needed an inertia correction): the point
         // that met the tolerance was written to `out` before the polish and is what is returned
-        st = CMPC_CONVERGED; kkt = ks; use_saved = true; break;
+        st = CMPC_CONVERGED | SAVED; kkt = ks; break;
       }
       if (polish < 0) {
         // best acceptable iterate so far (see the oracle): whatever ends the run, it is what is returned
@@ -2425,17 +2511,17 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         if (kkt <= tol) {
           // (the tolerance was met from a level >= MU_WARM: same snapshot)
           if (state_out && mu >= MU_WARM && unsnapped) { if (!PIPE || wv == 0) write_state(state_out, mu); snapped = 1.0; }
-          polish = POLISH_ITERS; mu = tol / 10;
+          polish = POLISH_ITERS; mu = tol_10;
         } else {
-          n_acc = (kkt <= ACC_FACTOR * tol) ? n_acc + 1 : 0;
-          if (n_acc >= ACC_ITERS) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; break; }
+          n_acc = (kkt <= tol_acc) ? n_acc + 1 : 0;
+          if (n_acc >= ACC_ITERS) { st = CMPC_ACCEPTABLE | SAVED; kkt = ks; break; }
           {
             // progress watch on the error of the current barrier problem (final barrier value: the KKT error); it
             // restarts whenever the barrier value changes (see the oracle)
-            const double kw = (mu <= tol / 10) ? kkt : ebar;
+            const double kw = (mu <= tol_10) ? kkt : ebar;
             if (kw < 0.5 * kb) { kb = kw; kkt_best = kw; since_best = 0; } else ++since_best;
             if (since_best >= NOPROG_ITERS && ks <= acc_tol()) {
-              st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; break;
+              st = CMPC_ACCEPTABLE | SAVED; kkt = ks; break;
             }
           }
         }
@@ -2444,7 +2530,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         // (a polish step that ends ABOVE the tolerance, with a larger error than the point that met it: that point,
         // written out before the polish, is what is returned -- see the oracle)
         st = CMPC_CONVERGED;
-        if (kkt > tol && kkt > ks) { kkt = ks; use_saved = true; }
+        if (kkt > tol && kkt > ks) { kkt = ks; st = CMPC_CONVERGED | SAVED; }
         break;
       }
       // a resumed solve still at the state's barrier value: the state does not fit this tick's problem
@@ -2454,7 +2540,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       const bool at_cap = it == it_cap;
       if (at_cap || !(kkt < INFINITY) || n_stall >= STALL_ITERS || stale) {
         if (polish >= 0) st = CMPC_CONVERGED;                   // (cap reached inside the polish)
-        else if (ks <= acc_tol() && !stale) { st = CMPC_ACCEPTABLE; kkt = ks; use_saved = true; }
+        else if (ks <= acc_tol() && !stale) { st = CMPC_ACCEPTABLE | SAVED; kkt = ks; }
         else st = (at_cap && !stale) ? CMPC_MAX_ITER : CMPC_NUMERICAL;
         break;
       }
@@ -2462,8 +2548,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       if (polish > 0) --polish;
       else if (!(resume && it == 0)) {          // (a resumed solve re-centres at the state's barrier value first: see the oracle)
         const double mu_before = mu;
-        while (mu > tol / 10 && ebar < 10 * mu)
-          mu = fmax(tol / 10, fmin(MU_FACTOR * mu, mu * sqrt(mu)));
+        while (mu > tol_10 && ebar < 10 * mu)
+          mu = fmax(tol_10, fmin(MU_FACTOR * mu, mu * sqrt(mu)));
         if (mu != mu_before) {                   // a new barrier problem: the progress watch restarts
           double inf = INFINITY;
           CMPC_OPAQUE_D(inf);
@@ -2495,6 +2581,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         CMPC_TICK(7);
       }
     }
+    const bool use_saved = (st & SAVED) != 0;
+    st &= SAVED - 1;
     if (!use_saved && (!PIPE || wv == 0)) write_solution(out);
     // (the verdict is the same in every lane; said so, the attempt loop is a uniform loop and what it carries -- the
     // iterations spent -- lives in a scalar register instead of a spilled vector one)

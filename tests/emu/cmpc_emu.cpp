@@ -115,6 +115,7 @@ extern "C" int cmpc_emu_solve_batch_state(const cmpc_spec *sp, int32_t B, const 
   ka.sp = *sp; ka.B = B; ka.recs = recs; ka.warm = warm; ka.out = out;
   ka.state_in = state_in; ka.state_out = state_out;
   ka.status = status; ka.iters = iters; ka.kkt = kkt; ka.prof = nullptr;
+  cmpc::fill_levels(ka);
   // (the 8-vertex solver is a two-wave workgroup: round 5's G'PG keeps one column of the stage block per lane, which one
   // wave of 64 lanes does not have for its 92 columns -- the one-wave form of rounds 2-4 is gone)
   const int nw8 = cmpc::WAVES_NV8;
