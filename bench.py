@@ -59,14 +59,16 @@ def measured_traffic(workload, batch, N):
     """HBM bytes per launch from the committed PMC runs (profiles/*traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 --pmc passes of this same command), or None."""
     import glob
-    best = None
+    best, key = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         if d.get("workload") == workload and d.get("batch") == batch and d.get("N") == N:
-            best = (d["hbm_bytes_per_launch"], os.path.basename(path))
+            k = (d.get("collected", ""), os.path.basename(path))        # the latest session (older files carry no date: by name)
+            if key is None or k > key:
+                best, key = (d["hbm_bytes_per_launch"], os.path.basename(path)), k
     return best
 
 

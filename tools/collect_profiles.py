@@ -1,7 +1,7 @@
 """Developer script: copy what tools/round_report.sh <tag> left under gpurun_out/<tag>/ into profiles/<tag>_* (the
 summaries the design documents cite; the raw rocprofv3 output stays in gpurun_out/, which is scratch).
 usage: python tools/collect_profiles.py r03c"""
-import csv, glob, json, os, shutil, sys
+import csv, glob, json, os, shutil, sys, time
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
@@ -57,6 +57,7 @@ if os.path.exists(tr):
     res["algorithmic_bytes_per_launch"] = line["roofline"]["algorithmic_bytes_per_solve"] * line["config"]["global_batch"]
     res["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
                       f"--steps 1 --warmup 0 --no-cpu-baseline --no-extras   (tools/profile_round.sh {tag})")
+    res["collected"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())
     json.dump(res, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 # whole-body QP kernel: statistics of three launches, HBM counters of one (16 B / lane accesses are not used there: the
 # FETCH_SIZE correction of the 8 B / lane calibration above applies to its row loads as well)
