@@ -140,6 +140,35 @@ def test_four_vertex_kernel_has_no_spill_code_in_its_stage_loops(tmp_path):
         elif ln.strip().startswith("scratch_"):
             worst, n = max(worst, depth), n + 1
     assert worst <= 3, f"{n} scratch instructions, deepest at loop depth {worst}: spill code inside a stage loop"
+    # Round 5.  (1) Every hand-written v_readfirstlane (CMPC_UNIFORM_D) stands between the wait states gfx950 asks for --
+    # the compiler pads the instructions it issues itself, not the text of an asm; unpadded, the low word of a number
+    # came from the register's previous value (one part in a million, found by the single == pair test).
+    asm_blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", body, flags=re.S)
+    rfl = [b for b in asm_blocks if "v_readfirstlane_b32" in b]
+    assert rfl, "CMPC_UNIFORM_D not found in the kernel"
+    for b in rfl:
+        ops = [ln.strip().split()[0] for ln in b.strip().splitlines() if ln.strip()]
+        assert ops[0] == "s_nop" and ops[-1] == "s_nop", b
+    # (2) The forward sweep's stage loop -- the innermost loop with the most global loads: it issues its factor loads a
+    # stage ahead -- never drains the memory pipeline: a vmcnt(0) there (a spill reload, a copy of a prefetched
+    # register, a load that looks freshly issued to the wait-count analysis) makes the prefetch a no-op.
+    lines = body.splitlines()
+    best = (0, 0)
+    for i, ln in enumerate(lines):
+        if "This Inner Loop Header: Depth=4" not in ln:
+            continue
+        start = max(k for k in range(i - 6, i) if re.match(r"^\.LBB\d+_\d+:", lines[k]))
+        label = lines[start].split(":")[0]                                   # ".LBB4_693"
+        ends = [k for k in range(start, len(lines)) if "branch" in lines[k] and lines[k].strip().endswith(label)]
+        if not ends:
+            continue
+        blk = [x.strip() for x in lines[start:ends[-1] + 1]]
+        n_loads = sum(x.startswith("global_load") for x in blk)
+        if n_loads > best[0]:
+            best = (n_loads, sum(1 for x in blk if x.startswith("s_waitcnt") and "vmcnt(0)" in x))
+    loads, drains = best
+    assert loads >= 60, loads
+    assert drains == 0, f"{drains} full drains of the memory pipeline inside the forward sweep's stage loop"
 
 
 def test_wave_reductions_take_no_lds_round_trip_and_the_qp_kernel_keeps_seven_instances_per_cu(tmp_path):
