@@ -66,6 +66,7 @@ typedef double cmpc_v4d __attribute__((ext_vector_type(4)));
 // optimiser can derive from the spec alone (2 w, w / 2, 1 - k1^2, ... -- some twenty products) it computes at kernel entry
 // and keeps in VECTOR registers through the whole solve (there is no scalar fp64 arithmetic), forty-five of them
 static __device__ __forceinline__ double cmpc_fresh(double a) { asm volatile("" : "+s"(a)); return a; }
+#define CMPC_FRESH_D(x) cmpc_fresh(x)
 #ifdef CMPC_FRESH_SPEC
 #define SPD(field) cmpc_fresh(sp.field)
 #else
@@ -107,6 +108,7 @@ static __device__ __forceinline__ double cmpc_uniform_d(double v) {
 #ifndef CMPC_RELANE
 #define CMPC_RELANE(x) do { } while (0)
 #define SPD(field) (sp.field)
+#define CMPC_FRESH_D(x) (x)
 #define CMPC_UNIFORM_D(x) (x)
 #endif
 // x * y + z in ONE rounding, spelled out.  Everywhere else the multiply-adds are formed by the compiler's contraction of
@@ -2411,7 +2413,9 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
   // ---------------------------------------------------------------------------------------
   CMPC_DEV void solve(const double *warm, const double *state_in, double *state_out, double *out, int32_t *status,
                       int32_t *iters, double *kkt_out) {
-    const double tol = sp.tol;
+    // (the tolerance where it is used, from its scalar register: as a local it was a vector register carried through the
+    // whole solve -- and the one spilled)
+    auto tol_ = [&]() { return CMPC_FRESH_D(sp.tol); };
     // (what the outer loop compares with, every lane the same value: scalar registers)
     const double tol_acc = ka.tol_acc, tol_10 = ka.tol_tenth;   // ACC_FACTOR * tol, tol / 10
     const double x0n2 = 0.0;                    // |hw_0|^2 is read from the record header in LDS where it is used
@@ -2447,7 +2451,15 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     {
       double inf = INFINITY, zero = 0.0;        // (materialised here: hoisted out of the instance loop they were spilled)
       CMPC_OPAQUE_D(inf); CMPC_OPAQUE_D(zero);
-      reg_last = zero; kkt_best = inf; kkt_saved = inf; snapped = zero;
+      // (second attempt: the acceptable point the failed resumed attempt left in `out` stays the level to beat -- see the end
+      // of the attempt and the oracle; every lane, and both waves of a pair, read before any of them writes)
+      const double ks0 = kkt_saved;
+      if constexpr (PIPE) { CMPC_SYNC_WG(); } else sync();
+      double at0 = sp.acc_tol;
+      CMPC_OPAQUE_D(at0);
+      const bool carry = spent > 0 && ks0 <= fmax(at0, tol_());
+      reg_last = zero; kkt_best = inf; snapped = zero;
+      if (!carry) kkt_saved = inf;
       if constexpr (CNT_LDS) { R(D::oCOLD + 4) = zero; R(D::oCOLD + 5) = zero; R(D::oCOLD + 6) = zero - 1.0; R(D::oCOLD + 7) = zero; }
     }
     // acceptable level; every iterate the acceptable-level counter counts is also saved (see the oracle).  Formed
@@ -2455,8 +2467,8 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
     // (the copy of the kernel argument is made opaque at every use: hoisted to kernel entry it sat in a vector register
     // pair through the whole solve and was spilled)
     auto acc_raw = [&]() { double a = sp.acc_tol; CMPC_OPAQUE_D(a); return a; };
-    auto acc_tol = [&]() { return fmax(acc_raw(), tol); };
-    auto save_tol = [&]() { return fmax(fmax(acc_raw(), tol), tol_acc); };
+    auto acc_tol = [&]() { return fmax(acc_raw(), tol_()); };
+    auto save_tol = [&]() { return fmax(fmax(acc_raw(), tol_()), tol_acc); };
     // (the pair: phases that walk the horizon serially belong to wave 0; the other wave waits at the next barrier)
     if (!PIPE || wv == 0) initial_point(resume ? state_in : warm, warm, resume);
     pair_sync();
@@ -2508,7 +2520,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
       if (polish < 0) {
         // best acceptable iterate so far (see the oracle): whatever ends the run, it is what is returned
         if (kkt <= save_tol() && kkt < ks) { if (!PIPE || wv == 0) write_solution(out); ks = kkt; kkt_saved = kkt; }
-        if (kkt <= tol) {
+        if (kkt <= tol_()) {
           // (the tolerance was met from a level >= MU_WARM: same snapshot)
           if (state_out && mu >= MU_WARM && unsnapped) { if (!PIPE || wv == 0) write_state(state_out, mu); snapped = 1.0; }
           polish = POLISH_ITERS; mu = tol_10;
@@ -2530,7 +2542,7 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         // (a polish step that ends ABOVE the tolerance, with a larger error than the point that met it: that point,
         // written out before the polish, is what is returned -- see the oracle)
         st = CMPC_CONVERGED;
-        if (kkt > tol && kkt > ks) { kkt = ks; st = CMPC_CONVERGED | SAVED; }
+        if (kkt > tol_() && kkt > ks) { kkt = ks; st = CMPC_CONVERGED | SAVED; }
         break;
       }
       // a resumed solve still at the state's barrier value: the state does not fit this tick's problem
@@ -2581,9 +2593,15 @@ template <int NV, int NW = 1, bool PIPE = false> struct Solver {
         CMPC_TICK(7);
       }
     }
-    const bool use_saved = (st & SAVED) != 0;
+    bool use_saved = (st & SAVED) != 0;
     st &= SAVED - 1;
-    if (!use_saved && (!PIPE || wv == 0)) write_solution(out);
+    // A resumed attempt that failed is followed by a plain one with the rest of the budget; an acceptable point it saved on
+    // the way is not given up: it stays in `out`, its error is the level the plain attempt has to beat, and with no budget
+    // left for a plain attempt it is the answer (see the oracle).
+    const double ks_end = kkt_saved;
+    const bool keep = resume && (st == CMPC_MAX_ITER || st == CMPC_NUMERICAL) && ks_end <= acc_tol();
+    if (keep && !(it < sp.max_iter)) { st = CMPC_ACCEPTABLE; kkt = ks_end; use_saved = true; }
+    if (!use_saved && !keep && (!PIPE || wv == 0)) write_solution(out);
     // (the verdict is the same in every lane; said so, the attempt loop is a uniform loop and what it carries -- the
     // iterations spent -- lives in a scalar register instead of a spilled vector one)
     const int again = CMPC_UNIFORM_INT((int)(resume && (st == CMPC_MAX_ITER || st == CMPC_NUMERICAL) && it < sp.max_iter));

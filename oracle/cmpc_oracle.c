@@ -665,14 +665,18 @@ static void write_solution(const prob_t *P, const work_t *W, double *out) {
 
 /* One interior-point solve.  out: X then U (reference layout). */
 static void solve_one_capped(const cmpc_spec *sp, const double *rec, const double *warm, double *out,
-                             stats_t *st, int verbose, double *full, const double *state_in, double *state_out, int cap);
+                             stats_t *st, int verbose, double *full, const double *state_in, double *state_out, int cap,
+                             double kkt_saved_in);
 static void solve_one(const cmpc_spec *sp, const double *rec, const double *warm, double *out,
                       stats_t *st, int verbose, double *full, const double *state_in, double *state_out) {
-  solve_one_capped(sp, rec, warm, out, st, verbose, full, state_in, state_out, sp->max_iter);
+  solve_one_capped(sp, rec, warm, out, st, verbose, full, state_in, state_out, sp->max_iter, INFINITY);
 }
 /* cap: iteration budget of this attempt (a resumed attempt and the plain one that may follow it share max_iter) */
+/* kkt_saved_in: error of the acceptable point a failed resumed attempt left in `out` (INFINITY: none) -- the plain attempt
+ * that follows it only replaces that point by a better one, and falls back on it like on a saved point of its own */
 static void solve_one_capped(const cmpc_spec *sp, const double *rec, const double *warm, double *out,
-                             stats_t *st, int verbose, double *full, const double *state_in, double *state_out, int cap) {
+                             stats_t *st, int verbose, double *full, const double *state_in, double *state_out, int cap,
+                             double kkt_saved_in) {
   prob_t Pb; prob_init(&Pb, sp, rec);
   const prob_t *P = &Pb;
   const int N = P->N, nx = P->nx, nu = P->nu, nz = P->nz, ni = P->ni;
@@ -729,7 +733,7 @@ static void solve_one_capped(const cmpc_spec *sp, const double *rec, const doubl
   int snapped = 0;
   st->status = CMPC_MAX_ITER; st->n_reg = 0; st->waste = 0.0;
   int it, n_acc = 0, n_stall = 0, polish = -1, since_best = 0, use_saved = 0;
-  double kkt_best = INFINITY, kkt_saved = INFINITY;
+  double kkt_best = INFINITY, kkt_saved = kkt_saved_in;
   const double acc_tol = fmax(sp->acc_tol, tol);
   /* every iterate the acceptable-level counter n_acc counts is also saved: with acc_tol < ACC_FACTOR * tol the
    * counter could otherwise end the run with nothing in `out` */
@@ -928,7 +932,18 @@ static void solve_one_capped(const cmpc_spec *sp, const double *rec, const doubl
     }
   }
   free(xn);
-  if (!use_saved) write_solution(P, W, out);
+  /* A resumed attempt that failed (stale state, collapsed steps, its share of the cap) is followed by a plain one with the
+   * rest of the budget.  An acceptable point it saved on the way is NOT given up (round-4 advisor: a tick that used to end
+   * "acceptable" could end at the cap): it stays in `out`, the plain attempt starts with its error as the level to beat,
+   * and with no budget left for a plain attempt it is the answer. */
+  const int failed_resume = resume && (st->status == CMPC_MAX_ITER || st->status == CMPC_NUMERICAL);
+#ifdef CMPC_ORACLE_DROP_SAVED_ON_RETRY        /* (the behaviour of rounds 3-5, for tests/tools that show the difference) */
+  const int keep_saved = 0;
+#else
+  const int keep_saved = failed_resume && kkt_saved <= acc_tol;
+#endif
+  if (keep_saved && !(it < sp->max_iter)) { st->status = CMPC_ACCEPTABLE; kkt = kkt_saved; use_saved = 1; }
+  if (!use_saved && !keep_saved) write_solution(P, W, out);
   if (full) {   /* x, lam ((N+1) x nx each), s, z ((N+1) x ni each) */
     memcpy(full, W->x, sizeof(double) * (N + 1) * nx); full += (N + 1) * nx;
     memcpy(full, W->lam, sizeof(double) * (N + 1) * nx); full += (N + 1) * nx;
@@ -955,7 +970,8 @@ static void solve_one_capped(const cmpc_spec *sp, const double *rec, const doubl
      * the iterations of both attempts are reported */
     const int spent = st->iters;
     if (spent < sp->max_iter) {                /* both attempts together stay within max_iter (+ 1: `iters` <= max_iter + 1) */
-      solve_one_capped(sp, rec, warm, out, st, verbose, full, NULL, state_out, sp->max_iter - spent);
+      solve_one_capped(sp, rec, warm, out, st, verbose, full, NULL, state_out, sp->max_iter - spent,
+                       keep_saved ? kkt_saved : INFINITY);
       st->iters += spent;
     }
   }

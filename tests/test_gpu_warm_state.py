@@ -174,3 +174,36 @@ def test_state_in_and_state_out_must_not_overlap():
     rc = lib.cmpc_solve_batch_state(solver._h, 4, d.data_ptr(), None, buf[0:4].data_ptr(), out.data_ptr(), buf[0:4].data_ptr(),
                                     st.data_ptr(), it.data_ptr(), kk.data_ptr(), None)
     assert rc != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_failed_resumed_attempts_keep_their_acceptable_point(oracle, kernel):
+    """512 instances resumed from ANOTHER instance's solver state with a budget of 30 iterations (the resumed attempt goes
+    stale or nowhere, the plain attempt gets what is left): the HIP kernels end like the oracle -- nothing that ends at the
+    cap or "numerical" had an acceptable point to fall back on, the verdict usable / not agrees on (nearly) every instance,
+    and as many instances end "acceptable" with the whole budget spent (the saved point of the failed attempt among them;
+    tests/test_emu_kernel.py has the three instances the rule was written for)."""
+    import dataclasses
+    spec, rec = wl.make_workload("randomized", B=512, N=20)
+    cs0 = oracle_spec(oracle, spec)
+    _, state, st0, _, _ = oracle.solve_batch_state(cs0, rec)
+    state = state[np.roll(np.arange(512), 1)]
+    spec = dataclasses.replace(spec, max_iter=30, kernel={"single": 1, "pair": 2}[kernel])
+    cs = oracle_spec(oracle, spec)
+    ref, _, st_r, it_r, kk_r = oracle.solve_batch_state(cs, rec, state=state)
+    s = BatchedCentroidalMPC(spec, device="cuda:0")
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    so = s.new_state(512)
+    out, st, it, kk = s.solve(dev(rec), state=dev(state), state_out=so)
+    torch.cuda.synchronize()
+    st, it, kk, out = st.cpu().numpy(), it.cpu().numpy(), kk.cpu().numpy(), out.cpu().numpy()
+    assert it.max() <= spec.max_iter + 1
+    bad = np.isin(st, (1, 2))
+    assert bad.any() and kk[bad].min() > spec.acc_tol             # no acceptable point was given up
+    ok, ok_r = np.isin(st, (0, 3)), np.isin(st_r, (0, 3))
+    assert (ok != ok_r).sum() <= 0.05 * 512, (int((ok != ok_r).sum()),)
+    at_cap, at_cap_r = (st == 3) & (it >= spec.max_iter), (st_r == 3) & (it_r >= spec.max_iter)
+    assert at_cap.sum() >= 0.7 * at_cap_r.sum() and kk[at_cap].max() <= spec.acc_tol
+    both = ok & ok_r & (st == st_r)
+    assert np.median(rel_inf(out[both], ref[both])) < 1e-6
