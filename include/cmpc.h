@@ -132,7 +132,9 @@ int cmpc_solve_batch(cmpc_handle *h, int32_t B, const double *params, const doub
  * reference's opt.set_initial(sol.value(...)) (code/centroidal_mpc_vertices.py:630-631), which IPOPT likewise uses
  * for the primal variables only.  A resumed solve whose state does not fit this tick's problem (still at the state's
  * barrier value after 20 iterations, or ending without a usable point) is followed by the plain solve inside the same
- * call with what is left of max_iter; iters[] reports both attempts.
+ * call with what is left of max_iter; iters[] reports both attempts.  A point within acc_tol that the resumed attempt
+ * had in hand is not given up: the plain solve replaces it only by a better one, and it is returned (CMPC_ACCEPTABLE) when
+ * the plain solve finds none or has no iterations left.
  */
 int cmpc_solve_batch_state(cmpc_handle *h, int32_t B, const double *params, const double *warm_XU,
                            const double *state_in, double *out_XU, double *state_out, int32_t *status,
